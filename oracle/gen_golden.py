@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference's own Triton kernels on CPU.
+
+Usage (in the build container only; /root/reference does not exist on the GPU box):
+
+    cd /root/repo && TRITON_INTERPRET=1 PYTHONDONTWRITEBYTECODE=1 \
+        PYTHONPATH=/root/reference python oracle/gen_golden.py
+
+Writes ``tests/golden/<case>.npz``.  A fixture is DATA only: the seeded inputs and the outputs
+the reference produced for them (int8 tensors, fp32 scales, fp16/bf16 outputs stored as
+uint16 bit patterns, base-2 LSE).  Upstream pairings only:
+  per_block quantizer  <-> attn_qk_int8_per_block{,_causal}.forward
+  per_thread quantizer <-> attn_qk_int8_per_thread.forward (non-causal only)
+Reference call sites restated: sageattention/core.py:279-318.
+"""
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+import torch
+
+assert os.environ.get("TRITON_INTERPRET") == "1", "run with TRITON_INTERPRET=1"
+
+from sageattention.triton.quant_per_block import per_block_int8  # noqa: E402
+from sageattention.triton.quant_per_thread import per_thread_int8  # noqa: E402
+from sageattention.triton.attn_qk_int8_per_block import forward as attn_block  # noqa: E402
+from sageattention.triton.attn_qk_int8_per_block_causal import forward as attn_block_causal  # noqa: E402
+from sageattention.triton.attn_qk_int8_per_thread import forward as attn_thread  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+# name, B, Hq, Hk, M, N, D, layout, dtype, causal, k_bias
+CASES = [
+    ("c1_hnd", 2, 8, 8, 128, 128, 64, "HND", "fp16", False, 0.0),   # BASELINE configs[0]
+    ("c1_nhd", 2, 8, 8, 128, 128, 64, "NHD", "fp16", False, 0.0),
+    ("c1_causal", 2, 4, 4, 128, 128, 64, "HND", "fp16", True, 0.0),
+    ("d128_ragged", 1, 2, 2, 192, 192, 128, "HND", "fp16", False, 2.0),  # N not a multiple of 128
+    ("gqa_causal_320", 1, 8, 2, 320, 320, 64, "HND", "fp16", True, 1.0),
+    ("cross_100x200", 1, 2, 2, 100, 200, 64, "HND", "fp16", False, 0.0),  # M != N, ragged both
+    ("bf16_d128", 1, 2, 2, 256, 256, 128, "NHD", "bf16", False, 3.0),
+]
+
+
+def bits(x: torch.Tensor) -> np.ndarray:
+    if x.dtype in (torch.float16, torch.bfloat16):
+        return x.contiguous().view(torch.int16).numpy().view(np.uint16)
+    return x.contiguous().numpy()
+
+
+def run_quiet(fn, *a, **kw):
+    # the reference's per-thread forward prints shapes (attn_qk_int8_per_thread.py:203-204)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for i, (name, B, Hq, Hk, M, N, D, layout, dt, causal, kbias) in enumerate(CASES):
+        torch.manual_seed(1000 + i)
+        dtype = torch.float16 if dt == "fp16" else torch.bfloat16
+        shp = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
+        q = torch.randn(shp(Hq, M)).to(dtype)
+        k = torch.randn(shp(Hk, N))
+        if kbias:
+            bias_shape = (1, Hk, 1, D) if layout == "HND" else (1, 1, Hk, D)
+            k = k + kbias * torch.randn(bias_shape)  # channel outliers: exercises smooth_k
+        k = k.to(dtype)
+        v = torch.randn(shp(Hk, N)).to(dtype)
+        seq_dim = 2 if layout == "HND" else 1
+        km = k.mean(dim=seq_dim, keepdim=True)  # core.py:280
+        sm_scale = 1.0 / (D ** 0.5)
+        v16 = v.to(torch.float16)  # core.py:289-290
+
+        out = {"q": bits(q), "k": bits(k), "v": bits(v), "km": bits(km)}
+        # --- per-block pairing
+        qb, qsb, kb, ksb = per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=layout)
+        fwd = attn_block_causal if causal else attn_block
+        ob, lb = fwd(qb, kb, v16, qsb, ksb, tensor_layout=layout, output_dtype=dtype, return_lse=True)
+        out.update(pb_q8=qb.numpy(), pb_qs=qsb.numpy(), pb_k8=kb.numpy(), pb_ks=ksb.numpy(),
+                   pb_o=bits(ob), pb_lse2=lb.numpy())
+        # --- per-thread pairing (non-causal only: SURVEY 3.3)
+        qt, qst, kt, kst = per_thread_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=layout)
+        out.update(pt_q8=qt.numpy(), pt_qs=qst.numpy(), pt_k8=kt.numpy(), pt_ks=kst.numpy())
+        if not causal:
+            ot, lt = run_quiet(attn_thread, qt, kt, v16, qst, kst, sm_scale, tensor_layout=layout,
+                               output_dtype=dtype, return_lse=True)
+            out.update(pt_o=bits(ot), pt_lse2=lt.numpy())
+        meta = dict(B=B, Hq=Hq, Hk=Hk, M=M, N=N, D=D, layout=layout, dtype=dt, causal=int(causal),
+                    sm_scale=sm_scale)
+        out["meta"] = np.array([repr(meta)])
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {os.path.getsize(path)/1024:.0f} KiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()
