@@ -1,0 +1,183 @@
+/*
+ * sageattn_hip.h -- C ABI of the MI355X (gfx950) native SageAttention hot path.
+ *
+ * Drop-in boundary for the path sageattn() / sageattn_qk_int8_pv_{fp16,fp8}_* of
+ * eliotwang/SageAttention (sageattention/core.py:80-905).  Every entry point below replaces one
+ * or more functions that the reference binds through pybind (module names
+ * sageattention._fused and sageattention._qattn_{sm80,sm89,rocm}); the reference interface each
+ * one replaces is cited as file:line of the reference tree.  INTEGRATION.md shows the
+ * reference-side binding.
+ *
+ * Conventions
+ *  - plain C: device pointers, sizes, element strides; no torch types.  All pointers are DEVICE
+ *    pointers of the current HIP device unless stated otherwise.
+ *  - tensors are 4-D [B,H,N,D] views with unit stride on D, described by sage_tensor (strides in
+ *    ELEMENTS): this covers both reference layouts, tensor_layout 1 = "HND" [B,H,N,D] and
+ *    0 = "NHD" [B,N,H,D] (core.py:585; strides selected as in qk_int_sv_f16_cuda_sm80.cu:728-764).
+ *  - ownership as in the reference: the caller allocates every buffer, the callee
+ *    keeps no state; work is enqueued on `stream` and never synchronised.
+ *  - every function returns SAGE_OK (0) or a negative sage_status; nothing is printed, nothing
+ *    aborts (the reference raises through TORCH_CHECK / std::invalid_argument, utils.cuh:20-38).
+ */
+#ifndef SAGEATTN_HIP_H
+#define SAGEATTN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGEATTN_HIP_ABI_VERSION 1
+
+typedef void* sage_stream_t; /* hipStream_t */
+
+typedef enum sage_status {
+  SAGE_OK = 0,
+  SAGE_ERR_INVALID_ARGUMENT = -1, /* bad enum / null pointer / inconsistent sizes          */
+  SAGE_ERR_UNSUPPORTED_HEAD_DIM = -2, /* head_dim not in {64,128} (dispatch_utils.h:23-34)  */
+  SAGE_ERR_UNSUPPORTED = -3,      /* valid in the reference, not built here                */
+  SAGE_ERR_TOO_LARGE = -4,        /* a (b,h) slice exceeds the 2^31-byte buffer window       */
+  SAGE_ERR_LAUNCH = -5            /* hipGetLastError() != hipSuccess after the launch       */
+} sage_status;
+
+typedef enum sage_dtype { SAGE_F16 = 0, SAGE_BF16 = 1 } sage_dtype;
+
+/* csrc/qattn/attn_utils.cuh:49-54 (QuantGranularity); values cross the reference's pybind ABI as
+ * ints (core.py:587: per_warp = 2, per_thread = 3). */
+typedef enum sage_qk_gran {
+  SAGE_GRAN_PER_BLOCK = 1,
+  SAGE_GRAN_PER_WARP = 2,
+  SAGE_GRAN_PER_THREAD = 3
+} sage_qk_gran;
+
+/* Quantizer numerics: the reference has two statements of the INT8 quantizer that differ in the
+ * last bit. */
+typedef enum sage_rounding {
+  SAGE_ROUND_TRITON = 0, /* scale=amax/127 (+eps per-thread); q=trunc(x/scale + 0.5*sign);
+                            mean subtracted in the input dtype  (triton/quant_per_block.py:39-54) */
+  SAGE_ROUND_CUDA = 1    /* amax=max(1e-7,amax); q=rint_even(x*(127/amax)) saturated;
+                            mean subtracted in fp32              (csrc/fused/fused.cu:119-184)    */
+} sage_rounding;
+
+typedef struct sage_tensor {
+  void* data;
+  int64_t stride_b, stride_h, stride_n; /* elements */
+} sage_tensor;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int sage_abi_version(void);
+const char* sage_status_string(int status);
+/* Compile-time target of the device code in this library ("gfx950"). */
+const char* sage_target_arch(void);
+
+/* Process-wide tuning knobs (speed only, never results).  key SAGE_TUNE_NWAVES: waves per workgroup
+ * of the attention kernels, value in {0 = default, 4, 8}. */
+typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0 } sage_tune_key;
+int sage_set_tuning(int key, int value);
+
+/* ---- K smoothing ---------------------------------------------------------------------------
+ * km[b,h,:] = mean over n of k[b,h,n,:], fp32 accumulation, one rounding to `dtype`.
+ * Replaces the torch op `k.mean(dim=seq_dim, keepdim=True)` at core.py:612,794.
+ * workspace: fp32, at least sage_k_mean_workspace_bytes(B,H,N,D) bytes (deterministic two-pass
+ * reduction, no atomics).  km: [B,H,D] contiguous, same dtype as k. */
+size_t sage_k_mean_workspace_bytes(int B, int H, int N, int D);
+int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N, int D,
+                void* km, void* workspace, sage_stream_t stream);
+
+/* ---- INT8 Q/K quantizer ---------------------------------------------------------------------
+ * Replaces, by (gran, rounding, mean, mult):
+ *   quant_per_block_int8_cuda (2 overloads)        csrc/fused/fused.cu:429-592, pybind.cpp:23-25
+ *   quant_per_block_int8_fuse_sub_mean_cuda         csrc/fused/fused.cu:594-682
+ *   quant_per_warp_int8_cuda                        csrc/fused/fused.cu:685-768
+ *   triton per_block_int8 / per_thread_int8         sageattention/triton/quant_per_block.py:48,
+ *                                                   sageattention/triton/quant_per_thread.py:158
+ * x: [B,H,N,D] fp16/bf16;  out: int8 same logical shape;  scale: fp32 [B,H,G] contiguous with
+ *   per_block : G = ceil(N/blk)                     one scale per blk rows
+ *   per_warp  : G = ceil(N/blk)*(blk/warp)          one scale per warp rows
+ *   per_thread: is_key=0: G = ceil(N/blk)*(blk/warp)*8, rows with equal r%8 inside a warp group
+ *               is_key=1: G = ceil(N/blk)*(blk/warp)*4, rows with equal (r%8)/2
+ * mean: optional [B,H,D] (same dtype as x, contiguous) subtracted before quantization (smooth_k).
+ * mult: multiplied into x (fp32) before quantization (Q of the per-block path: sm_scale*log2e).
+ * lse_dot/lse_dot_vec: optional; lse_dot[b,h,n] = sum_d x[b,h,n,d]*lse_dot_vec[b,h/dot_group,d]
+ *   in fp32 (the `q @ km^T` LSE correction of core.py:613-617), fp32 [B,H,N] contiguous.
+ * blk in {64,128}; warp in {16,32,64} and divides blk; D in {64,128}. */
+int sage_quant_qk_int8(const sage_tensor* x, int dtype, int B, int H, int N, int D,
+                       const void* mean, const sage_tensor* out, float* scale,
+                       int gran, int is_key, int blk, int warp, float mult, int rounding,
+                       const void* lse_dot_vec, int dot_group, float* lse_dot,
+                       sage_stream_t stream);
+
+/* ---- V smoothing for the fp16-accumulate path ---------------------------------------------------
+ * out = fp16(v - vm) with vm [B,H,D] (dtype of v).  Replaces sub_mean_cuda, fused.cu:770-848. */
+int sage_sub_mean_f16(const sage_tensor* v, int dtype, int B, int H, int N, int D,
+                      const void* vm, const sage_tensor* out, sage_stream_t stream);
+
+/* ---- FP8 V quantizer ------------------------------------------------------------------------
+ * Replaces transpose_pad_permute_cuda + scale_fuse_quant_cuda / mean_scale_fuse_quant_cuda
+ * (csrc/fused/fused.cu:850-1083, sageattention/quant.py:225-322) in one fused pair of kernels.
+ * v: [B,H,N,D] fp16/bf16.  v_fp8: OCP e4m3fn bytes, logical [B,H,D,Npad] with Npad=ceil64(N),
+ * described by (stride_b, stride_h, stride_n:=stride of the D index); zero beyond N.
+ * v_scale[b,h,d] = amax_d/scale_max (fp32 [B,H,D]); v_mean (optional, fp32 [B,H,D]): when non
+ * null the channel mean (sum/ceil16(N), fused.cu:335,381) is subtracted first.
+ * The reference's 16-row permutation (quant.py:234) is an NVIDIA mma-fragment artefact and is
+ * not applied (the fork's HIP port disables it too, fused.hip:362-367).
+ * workspace: sage_quant_v_fp8_workspace_bytes(B,H,N,D) bytes. */
+size_t sage_quant_v_fp8_workspace_bytes(int B, int H, int N, int D);
+int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D,
+                     const sage_tensor* v_fp8, float* v_scale, float* v_mean, float scale_max,
+                     void* workspace, sage_stream_t stream);
+
+/* ---- fused attention, INT8 QK^T + FP16 PV ------------------------------------------------------
+ * Replaces qk_int8_sv_f16_accum_f32_attn, qk_int8_sv_f16_accum_f16_attn,
+ * qk_int8_sv_f16_accum_f16_attn_inst_buf, qk_int8_sv_f16_accum_f16_fuse_v_mean_attn
+ * (csrc/qattn/attn_cuda_sm80.h:19-65, qk_int_sv_f16_cuda_sm80.cu:674-1379).  On gfx950 the PV
+ * MFMA accumulates in fp32 for every pv_accum_dtype the reference names.
+ *   q8 [B,Hq,M,D] int8, k8 [B,Hk,N,D] int8, v [B,Hk,N,D] fp16 (or bf16, converted on the fly as
+ *   core.py:633 `v.to(float16)`), o [B,Hq,M,D] fp16/bf16 (o_dtype).
+ *   q_scale / k_scale: fp32 [B,Hq,Gq] / [B,Hk,Gk] with the shapes sage_quant_qk_int8 produces for
+ *   (gran, blkq, warpq, blkk=64, warpk=64)  (…sm80.cu:796-805).
+ *   sm_scale: logits are multiplied by sm_scale*log2(e) inside the kernel (…sm80.cu:92).
+ *   logit_mult_is_one != 0: the scales already contain sm_scale*log2e (triton per_block path,
+ *   attn_qk_int8_per_block.py:47) and sm_scale is ignored.
+ *   v_mean: optional fp32 [B,Hk,D] added to the output rows (fuse_v_mean).
+ *   lse: optional fp32 [B,Hq,M]; receives log2-domain lse of the scaled, smoothed logits
+ *   (…sm80.cu:657-668); the caller applies core.py:651.
+ *   is_causal: kv_idx > q_idx masked (top-left aligned, attn_utils.cuh:296-323). */
+int sage_attn_qk_int8_pv_f16(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v,
+                             int v_dtype, const sage_tensor* o, int o_dtype,
+                             const float* q_scale, const float* k_scale, const float* v_mean,
+                             float* lse, int B, int Hq, int Hk, int M, int N, int D,
+                             int is_causal, int qk_gran, int blkq, int warpq,
+                             float sm_scale, int logit_mult_is_one, sage_stream_t stream);
+
+/* ---- fused attention, INT8 QK^T + FP8 PV -------------------------------------------------------
+ * Replaces qk_int8_sv_f8_accum_f32[_fuse_v_scale][_fuse_v_mean]_attn[_inst_buf] and
+ * qk_int8_sv_f8_accum_f16_* (csrc/qattn/attn_cuda_sm89.h, qk_int_sv_f8_cuda_sm89.cuh:44-713) and the
+ * fork's unfused qk_int8_sv_f8_accum_f32_attn (csrc/qattn/rocm/attn_rocm_gfx942.h:20-32).
+ *   v_fp8: as produced by sage_quant_v_fp8 ([B,Hk,D,Npad], OCP e4m3fn);  v_scale fp32 [B,Hk,D]
+ *   multiplied into the output columns (fuse_v_scale), v_mean optional. */
+int sage_attn_qk_int8_pv_f8(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v_fp8,
+                            const sage_tensor* o, int o_dtype,
+                            const float* q_scale, const float* k_scale, const float* v_scale,
+                            const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N,
+                            int D, int is_causal, int qk_gran, int blkq, int warpq,
+                            float sm_scale, int logit_mult_is_one, sage_stream_t stream);
+
+/* ---- ring attention merge (new; the reference only exposes return_lse, core.py:122-124) -------
+ * In place: (o_acc, lse_acc) <- merge((o_acc, lse_acc), (o_blk, lse_blk)) with
+ *   lse = logaddexp(lse_a, lse_b);  o = o_a*exp(lse_a-lse) + o_b*exp(lse_b-lse).
+ * o_acc: fp32 [rows, D] contiguous; lse_acc / lse_blk: fp32 [rows] natural log;
+ * o_blk: fp16/bf16 [rows, D] contiguous. */
+int sage_merge_attn_states(float* o_acc, float* lse_acc, const void* o_blk, int o_dtype,
+                           const float* lse_blk, int64_t rows, int D, sage_stream_t stream);
+
+/* lse_out[i] = lse2[i]/log2(e) + (corr ? corr[i]*sm_scale : 0)   (core.py:651), n elements. */
+int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out,
+                    int64_t n, sage_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGEATTN_HIP_H */

@@ -1,0 +1,11 @@
+"""sageattention_amd -- MI355X (gfx950) native drop-in for the SageAttention quantized attention operator.
+
+Exports the names the reference package exports (sageattention/__init__.py:25-95): ``sageattn`` plus the
+``sageattn_qk_int8_*`` entry points that diffusers imports by name."""
+from .core import (sageattn, sageattn_qk_int8_pv_fp16_cuda, sageattn_qk_int8_pv_fp16_triton,
+                   sageattn_qk_int8_pv_fp8_cuda, sageattn_qk_int8_pv_fp8_cuda_sm90, sageattn_varlen)
+from . import quant, _qattn  # noqa: F401
+
+__all__ = ["sageattn", "sageattn_qk_int8_pv_fp16_cuda", "sageattn_qk_int8_pv_fp16_triton",
+           "sageattn_qk_int8_pv_fp8_cuda", "sageattn_qk_int8_pv_fp8_cuda_sm90", "sageattn_varlen"]
+__version__ = "0.1.0"

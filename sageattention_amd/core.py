@@ -1,0 +1,227 @@
+"""Host-side mirror of ``sageattention/core.py`` (reference) for MI355X / gfx950.
+
+Same public names, arguments, defaults, return values and error behaviour as the reference entry points
+(``sageattn`` core.py:80, ``sageattn_qk_int8_pv_fp16_triton`` :161, ``sageattn_qk_int8_pv_fp16_cuda`` :480,
+``sageattn_qk_int8_pv_fp8_cuda`` :656, ``sageattn_qk_int8_pv_fp8_cuda_sm90`` :908).  Everything below the
+argument handling runs as hand-written HIP through the C ABI (include/sageattn_hip.h): K mean, INT8 quantizers
+(with the LSE correction fused), V fp16/fp8 preparation and the fused attention kernel.  No Triton, no
+rocWMMA, no debug dumps (the fork's torch.save side effects, core.py:320-352,845-881, are not reproduced)."""
+import warnings
+from typing import Any, Optional
+
+import torch
+
+from . import _lib as L
+from . import _qattn
+from .quant import _quant, k_mean, per_channel_fp8, sub_mean
+
+__all__ = ["sageattn", "sageattn_qk_int8_pv_fp16_cuda", "sageattn_qk_int8_pv_fp16_triton",
+           "sageattn_qk_int8_pv_fp8_cuda", "sageattn_qk_int8_pv_fp8_cuda_sm90", "sageattn_varlen"]
+
+
+def _common_checks(q, k, v):
+    dtype = q.dtype
+    assert q.is_cuda, "Input tensors must be on cuda."
+    assert dtype in [torch.float16, torch.bfloat16], "Input tensors must be in dtype of torch.float16 or torch.bfloat16"
+    assert q.device == k.device == v.device, "All tensors must be on the same device."
+    assert q.dtype == k.dtype == v.dtype, "All tensors must have the same dtype."
+    return dtype
+
+
+def _pad_head_dim(q, k, v):
+    """core.py:590-601"""
+    head_dim_og = q.size(-1)
+    if head_dim_og < 64:
+        pad = 64 - head_dim_og
+    elif 64 < head_dim_og < 128:
+        pad = 128 - head_dim_og
+    elif head_dim_og > 128:
+        raise ValueError(f"Unsupported head_dim: {head_dim_og}")
+    else:
+        pad = 0
+    if pad:
+        q = torch.nn.functional.pad(q, (0, pad))
+        k = torch.nn.functional.pad(k, (0, pad))
+        v = torch.nn.functional.pad(v, (0, pad))
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    return q, k, v, head_dim_og
+
+
+def _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, want_lse_corr, Hq, Hk):
+    """Quantize Q and K (core.py:621-624) and, when asked, produce the LSE correction q.km (core.py:613-617)
+    inside the Q quantizer's pass over Q."""
+    dot_vec = km if (want_lse_corr and km is not None) else None
+    grp = Hq // Hk
+    if qk_quant_gran == "per_block":  # triton path: sm_scale*log2e folded into Q (quant_per_block.py:84)
+        q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_BLOCK, False, 128, 128, sm_scale * 1.44269504, L.ROUND_TRITON,
+                              dot_vec=dot_vec, dot_group=grp)
+        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km)
+    elif qk_quant_gran == "per_warp":
+        q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_WARP, False, 128, WARPQ, 1.0, L.ROUND_CUDA,
+                              dot_vec=dot_vec, dot_group=grp)
+        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km)
+    elif qk_quant_gran == "per_thread":
+        q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_THREAD, False, 128, WARPQ, 1.0, L.ROUND_TRITON,
+                              dot_vec=dot_vec, dot_group=grp)
+        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km)
+    else:
+        raise ValueError(f"Unsupported qk_quant_gran: {qk_quant_gran}")
+    return q8, qs, k8, ks, corr
+
+
+def _finish_lse(lse2, corr, sm_scale):
+    """core.py:651: lse / 1.44269504 + lse_correction * sm_scale"""
+    out = torch.empty_like(lse2)
+    L.check(L.lib().sage_finish_lse(lse2.data_ptr(), L.ptr(corr), float(sm_scale), out.data_ptr(), lse2.numel(),
+                                    L.stream_ptr(lse2.device)), "sage_finish_lse")
+    return out
+
+
+_GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_warp": L.GRAN_PER_WARP, "per_thread": L.GRAN_PER_THREAD}
+
+
+def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smooth_k, smooth_v, return_lse, WARPQ=32):
+    dtype = q.dtype
+    with torch.cuda.device(q.device):  # the reference's torch.cuda.set_device(v.device) workaround, core.py:583
+        q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+        if sm_scale is None:
+            sm_scale = head_dim_og ** -0.5
+        _, Hq, _, _ = L.dims(q, tensor_layout)
+        _, Hk, _, _ = L.dims(k, tensor_layout)
+        km = k_mean(k, tensor_layout) if smooth_k else None
+        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, return_lse, Hq, Hk)
+        o = torch.empty(q.size(), dtype=dtype, device=q.device)
+        vm = None
+        if smooth_v:
+            v, vm = sub_mean(v, tensor_layout)
+        lse2 = _qattn._attn_f16(q8, k8, v, o, qs, ks, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
+                                _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse),
+                                logit_mult_is_one=(qk_quant_gran == "per_block"))
+        o = o[..., :head_dim_og]
+        if return_lse:
+            return o, _finish_lse(lse2, corr if smooth_k else None, sm_scale)
+        return o
+
+
+@torch.compiler.disable
+def sageattn_qk_int8_pv_fp16_cuda(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    tensor_layout: str = "HND",
+    is_causal: bool = False,
+    qk_quant_gran: str = "per_thread",
+    sm_scale: Optional[float] = None,
+    pv_accum_dtype: str = "fp32",
+    smooth_k: bool = True,
+    smooth_v: bool = False,
+    return_lse: bool = False,
+    **kwargs: Any,
+) -> torch.Tensor:
+    """SageAttention with INT8 Q/K and FP16 PV (reference core.py:480-653).
+
+    On gfx950 the PV MFMA (v_mfma_f32_32x32x16_f16) accumulates in fp32 for every ``pv_accum_dtype`` the
+    reference names ("fp32", "fp16", "fp16+fp32"); ``smooth_v`` is honoured only for "fp16" as in the reference
+    (core.py:628-630) -- it is numerically a no-op with an fp32 accumulator, but kept for API parity.
+    Unknown keyword arguments (SDPA's ``attn_mask=``, ``dropout_p=`` ...) are accepted and ignored, as in the
+    reference (core.py:492)."""
+    _common_checks(q, k, v)
+    assert qk_quant_gran in ["per_warp", "per_thread"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    if pv_accum_dtype not in ("fp32", "fp16", "fp16+fp32"):
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
+    if pv_accum_dtype in ["fp32", "fp16+fp32"] and smooth_v:
+        warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")
+        smooth_v = False
+    warpq = 16 if (q.size(-1) > 64 and pv_accum_dtype == "fp16+fp32") else 32  # core.py:622
+    return _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smooth_k, smooth_v, return_lse, warpq)
+
+
+@torch.compiler.disable
+def sageattn_qk_int8_pv_fp16_triton(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    tensor_layout: str = "HND",
+    quantization_backend: str = "triton",
+    is_causal: bool = False,
+    attn_mask: Optional[torch.Tensor] = None,
+    sm_scale: Optional[float] = None,
+    smooth_k: bool = True,
+    return_lse: bool = False,
+    **kwargs: Any,
+) -> torch.Tensor:
+    """Reference core.py:161-360 (per-block INT8, FP16 PV).  Same numerics contract, served by the HIP kernels:
+    per-block quantization with sm_scale*log2e folded into Q.  ``attn_mask`` is a SURVEY 8(f2) "next" item."""
+    _common_checks(q, k, v)
+    if attn_mask is not None:
+        raise NotImplementedError("attn_mask is not supported by the gfx950 kernels yet (SURVEY.md 8f2)")
+    if quantization_backend not in ("triton", "cuda"):
+        raise ValueError(f"Unsupported quantization backend: {quantization_backend}")
+    return _sage_fp16(q, k, v, tensor_layout, is_causal, "per_block", sm_scale, smooth_k, False, return_lse)
+
+
+@torch.compiler.disable
+def sageattn_qk_int8_pv_fp8_cuda(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    tensor_layout: str = "HND",
+    is_causal: bool = False,
+    qk_quant_gran: str = "per_thread",
+    sm_scale: Optional[float] = None,
+    pv_accum_dtype: str = "fp32+fp16",
+    smooth_k: bool = True,
+    smooth_v: bool = False,
+    return_lse: bool = False,
+    **kwargs: Any,
+) -> torch.Tensor:
+    """SageAttention with INT8 Q/K and FP8 (OCP e4m3fn) PV, fp32 accumulation (reference core.py:656-905).
+    All of "fp32", "fp32+fp32", "fp32+fp16" accumulate in true fp32 on MFMA (no fp22 accumulator issue, so no
+    two-level buffer); V is quantized per channel with scale_max 448 (quant.py:228)."""
+    dtype = _common_checks(q, k, v)
+    assert qk_quant_gran in ["per_warp", "per_thread"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    if pv_accum_dtype not in ("fp32", "fp32+fp32", "fp32+fp16"):
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
+    if pv_accum_dtype in ("fp32+fp32", "fp32+fp16") and smooth_v:
+        warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")
+        smooth_v = False
+    with torch.cuda.device(q.device):
+        q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+        if sm_scale is None:
+            sm_scale = head_dim_og ** -0.5
+        _, Hq, _, _ = L.dims(q, tensor_layout)
+        _, Hk, _, _ = L.dims(k, tensor_layout)
+        km = k_mean(k, tensor_layout) if smooth_k else None
+        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, 32, return_lse, Hq, Hk)
+        o = torch.empty(q.size(), dtype=dtype, device=q.device)
+        v8, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+        lse2 = _qattn._attn_f8(q8, k8, v8, o, qs, ks, v_scale, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
+                               _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse))
+        o = o[..., :head_dim_og]
+        if return_lse:
+            return o, _finish_lse(lse2, corr if smooth_k else None, sm_scale)
+        return o
+
+
+@torch.compiler.disable
+def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout="HND", is_causal=False, qk_quant_gran="per_thread",
+                                      sm_scale=None, pv_accum_dtype="fp32+fp32", smooth_k=True, return_lse=False,
+                                      **kwargs):
+    """Reference core.py:908-1065 (Hopper TMA/wgmma variant).  Same operator; served by the gfx950 FP8 kernel."""
+    return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal,
+                                        qk_quant_gran=qk_quant_gran, sm_scale=sm_scale, pv_accum_dtype=pv_accum_dtype,
+                                        smooth_k=smooth_k, smooth_v=False, return_lse=return_lse)
+
+
+def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
+             sm_scale: Optional[float] = None, return_lse: bool = False, **kwargs: Any):
+    """Drop-in for ``F.scaled_dot_product_attention`` (reference core.py:80-144).  On MI355X this selects the
+    INT8-QK / FP16-PV kernel with fp32 accumulation (the upstream choice for architectures without a faster
+    FP8 tensor path, core.py:148; on gfx950 the non-scaled FP8 MFMA runs at the FP16 rate)."""
+    return sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                                         return_lse=return_lse, pv_accum_dtype="fp32")
+
+
+def sageattn_varlen(*args, **kwargs):
+    """Reference core.py:363-477.  Out of the round-1 hot-path scope."""
+    raise NotImplementedError("sageattn_varlen is not built yet on gfx950 (SURVEY.md 8f3)")

@@ -1,0 +1,395 @@
+// Fused INT8-QK^T -> online softmax -> FP16/FP8-PV attention for gfx950 (MI355X, CDNA4).
+//
+// Replaces the tile loop of csrc/qattn/qk_int_sv_f16_cuda_sm80.cu:44-671 and
+// csrc/qattn/qk_int_sv_f8_cuda_sm89.cuh:44-713 (semantics), designed for wave64 + MFMA:
+//
+//  * one wave owns 32 query rows; a workgroup of NWAVES waves owns NWAVES*32 rows and shares the
+//    K/V tiles (64 keys) through a double-buffered LDS ring, register-staged (global -> VGPR early,
+//    VGPR -> LDS after the PV MFMAs) so HBM/L2 latency hides under the MFMA phases.
+//  * S^T = K . Q^T on v_mfma_i32_32x32x32_i8 (A = K tile rows from LDS via ds_read_b128, B = Q^T held in
+//    registers for the whole kernel).  With this orientation every lane owns ONE query row
+//    (column of S^T): 32 of the 64 scores of its row sit in its own registers, the other 32 in
+//    lane^32, so the row max needs one v_permlane32_swap and the row sum none until the end.
+//  * P^T stays in registers: the fp32 accumulator layout of S^T is, after a packed fp16 convert,
+//    exactly the B operand of O^T += V^T . P^T on v_mfma_f32_32x32x16_f16; V^T fragments come
+//    from the row-major V tile in LDS through ds_read_b64_tr_b16 (hardware transpose).
+//  * O^T (d in registers, query row on the lane) is rescaled per lane, normalised and stored.
+//
+// Roofline: MFMA (4*M*N*D flop per (b,h); half int8 at 2x the fp16 rate), VALU/exp2 co-limited.
+// Algorithmic HBM bytes per (b,h): M*D (Q) + N*D (K) + 2*N*D (V fp16) + 2*M*D (O) + scales.
+#include "sage_common.h"
+
+namespace sage {
+
+struct AttnParams {
+  const int8_t* q; int64_t qsb, qsh, qsn;
+  const int8_t* k; int64_t ksb, ksh, ksn;
+  const uint8_t* v; int64_t vsb, vsh, vsn;  // byte pointer; strides in ELEMENTS of v's dtype
+  uint16_t* o; int64_t osb, osh, osn;
+  const float* q_scale; const float* k_scale; const float* v_scale; const float* v_mean;
+  float* lse;
+  int B, Hq, Hk, M, N;
+  int nqb;      // query blocks per (b,h)
+  int gq, gk;   // scales per (b,h)
+  int qgran, blkq, warpq;
+  float logit_mult;
+};
+
+__device__ __forceinline__ float swap_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int D>
+__device__ __forceinline__ int k_swz(int row) {
+  // 16-B chunk XOR that makes the ds_read_b128 A-fragment reads conflict free
+  if constexpr (D == 128) return (row >> 1) & 7; else return (row >> 2) & 3;
+}
+template <int D>
+__device__ __forceinline__ int v_win_swz(int row) {
+  // 64-B window XOR for the fp16 V tile so that the 4 rows of a tr-read land on 4 windows
+  if constexpr (D == 128) return row & 3; else return (row >> 1) & 1;
+}
+
+template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool OUT_BF16, bool V_BF16>
+__global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnParams p) {
+  constexpr int T = NWAVES * 64;
+  constexpr int QB = NWAVES * 32;
+  constexpr int KS = D / 32;          // k-steps of the int8 QK^T MFMA
+  constexpr int DT = D / 32;          // 32-wide d tiles of O^T
+  constexpr int KBYTES = 64 * D;      // one K tile (int8)
+  constexpr int VBYTES = 64 * D * 2;  // one V tile (fp16)
+  constexpr int KCH = D / 16;         // 16-B chunks per K row
+  constexpr int VCH = D / 8;          // 16-B chunks per V row
+  constexpr int KC = (64 * KCH + T - 1) / T;  // chunks per thread
+  constexpr int VC = (64 * VCH) / T;
+  static_assert((64 * VCH) % T == 0, "V tile must divide over the workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const k_lds = smem;
+  char* const v_lds = smem + 2 * KBYTES;
+
+  // ---- block -> (b, h, q block), XCD aware: consecutive logical ids (same head) share an L2
+  const int nwg = gridDim.x;
+  int lid;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+  }
+  int qb = lid % p.nqb;
+  const int bh = lid / p.nqb;
+  const int h = bh % p.Hq, b = bh / p.Hq;
+  if constexpr (CAUSAL) qb = p.nqb - 1 - qb;  // heaviest blocks first
+  const int hk = h / (p.Hq / p.Hk);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int q0 = qb * QB + wave * 32;
+  const int row = q0 + r;
+  const int rowc = min(row, p.M - 1);
+
+  // ---- Q^T fragments (B operand), resident for the whole kernel
+  v4i qf[KS];
+  {
+    const int8_t* qp = p.q + b * p.qsb + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qp + 32 * ks);
+  }
+  // ---- per-row q scale (…sm80.cu:103-117 index maps, evaluated once per lane)
+  float qsc;
+  {
+    int qi;
+    if (p.qgran == SAGE_GRAN_PER_BLOCK) qi = rowc / p.blkq;
+    else if (p.qgran == SAGE_GRAN_PER_WARP) qi = rowc / p.warpq;
+    else qi = (rowc / p.warpq) * 8 + (rowc & 7);
+    qsc = p.q_scale[((int64_t)b * p.Hq + h) * p.gq + qi] * p.logit_mult;
+  }
+  const float* ksp = p.k_scale + ((int64_t)b * p.Hk + hk) * p.gk;
+
+  // ---- tile range
+  const int kv_end = CAUSAL ? min(p.N, (qb + 1) * QB) : p.N;
+  const int ntiles = (kv_end + 63) >> 6;
+  const int wave_tiles = CAUSAL ? min(ntiles, ((q0 + 31) >> 6) + 1) : ntiles;
+
+  // ---- staging (global -> regs -> LDS)
+  const int8_t* kg = p.k + b * p.ksb + hk * p.ksh;
+  const uint8_t* vg = p.v + (b * p.vsb + hk * p.vsh) * 2;
+  uint4 kreg[KC], vreg[VC];
+  auto load_tile = [&](int j) {
+    const int n0 = j << 6;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      const int c = tid + i * T;
+      if (KC * T == 64 * KCH || c < 64 * KCH) {
+        const int kr = min(n0 + c / KCH, p.N - 1);  // clamped: masked in the softmax
+        kreg[i] = *reinterpret_cast<const uint4*>(kg + (int64_t)kr * p.ksn + (c % KCH) * 16);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+      const int c = tid + i * T;
+      const int vr = n0 + c / VCH;
+      vreg[i] = make_uint4(0, 0, 0, 0);  // rows >= N must be ZERO (0 * garbage could be NaN)
+      if (vr < p.N) vreg[i] = *reinterpret_cast<const uint4*>(vg + ((int64_t)vr * p.vsn + (c % VCH) * 8) * 2);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      const int c = tid + i * T;
+      if (KC * T == 64 * KCH || c < 64 * KCH) {
+        const int kr = c / KCH, cc = c % KCH;
+        *reinterpret_cast<uint4*>(k_lds + buf * KBYTES + kr * D + ((cc ^ k_swz<D>(kr)) << 4)) = kreg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+      const int c = tid + i * T;
+      const int vr = c / VCH, cc = c % VCH;
+      uint4 u = vreg[i];
+      if constexpr (V_BF16) {  // core.py:633 `v.to(torch.float16)`, fused into the staging pass
+        float f[8];
+        unpack8<true>(u, f);
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          w[e] = (uint32_t)f32_to_elem_bits<false>(f[2 * e]) | ((uint32_t)f32_to_elem_bits<false>(f[2 * e + 1]) << 16);
+        u = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      *reinterpret_cast<uint4*>(v_lds + buf * VBYTES + vr * (2 * D) + ((((cc >> 2) ^ v_win_swz<D>(vr))) << 6) +
+                                ((cc & 3) << 4)) = u;
+    }
+  };
+
+  // ---- lane-constant LDS read offsets
+  int k_rd[KS];  // K A-fragment: row r (+32*mt via immediate), chunk 2*ks+hh
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * D + (((2 * ks + hh) ^ k_swz<D>(r)) << 4);
+  int v_rd[DT];  // V^T fragment via tr-read: row 4*hh + q4 (+32*mt+16*s(+8) immediate), window dt
+  {
+    const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g = (lane >> 4) & 1;
+    const int rv = 4 * hh + q4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) v_rd[dt] = rv * (2 * D) + ((dt ^ v_win_swz<D>(rv)) << 6) + 32 * g + 8 * p4;
+  }
+
+  // ---- state
+  v16f acc_o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_o[dt][e] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int buf = j & 1;
+    const int n0 = j << 6;
+    if (j + 1 < ntiles) load_tile(j + 1);
+
+    if (j < wave_tiles) {
+      // ---- S^T = K . Q^T  (2 tiles of 32 keys x 32 query rows)
+      v16i s_acc[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s_acc[mt][e] = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const v4i a = *reinterpret_cast<const v4i*>(k_lds + buf * KBYTES + mt * 32 * D + k_rd[ks]);
+          s_acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s_acc[mt], 0, 0, 0);
+        }
+      }
+      // ---- dequantisation scales of this tile
+      float sc0, sc1;
+      if constexpr (KTHREAD) {  // …sm80.cu:131: 4 scales per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
+        sc0 = qsc * ksp[j * 4 + 2 * hh];
+        sc1 = qsc * ksp[j * 4 + 2 * hh + 1];
+      } else {
+        sc0 = sc1 = qsc * ksp[j];
+      }
+      // ---- logits (base 2), masks
+      float t[2][16];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[mt][e] = (float)s_acc[mt][e] * ((e & 2) ? sc1 : sc0);
+      const bool need_mask = (n0 + 64 > p.N) || (CAUSAL && (n0 + 63 > q0));
+      if (need_mask) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            const bool bad = (kv >= p.N) || (CAUSAL && kv > row);
+            t[mt][e] = bad ? -INFINITY : t[mt][e];
+          }
+      }
+      // ---- online softmax (attn_utils.cuh:354-458), one query row per lane
+      float mx = t[0][0];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[mt][e]);
+      mx = swap_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      v8h pf[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(t[mt][8 * s + e] - m_new);
+            const float p1 = __builtin_amdgcn_exp2f(t[mt][8 * s + e + 1] - m_new);
+            psum += p0 + p1;
+            v2f pp = {p0, p1};
+            const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
+            pf[mt][s][e] = ph[0];
+            pf[mt][s][e + 1] = ph[1];
+          }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[dt][e] *= alpha;
+      // ---- O^T += V^T . P^T
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const char* base = v_lds + buf * VBYTES + (32 * mt + 16 * s) * (2 * D) + v_rd[dt];
+            const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4s_vs*)(base));
+            const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
+            v8h a;
+            a.s0123 = __builtin_bit_cast(v4h, lo);
+            a.s4567 = __builtin_bit_cast(v4h, hi);
+            acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[mt][s], acc_o[dt], 0, 0, 0);
+          }
+    }
+
+    if (j + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
+  const float l_tot = swap_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  if (row < p.M) {
+    uint16_t* op = p.o + b * p.osb + h * p.osh + (int64_t)row * p.osn;
+    const float* vmp = p.v_mean ? p.v_mean + ((int64_t)b * p.Hk + hk) * D : nullptr;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[e] = acc_o[dt][4 * g4 + e] * inv;
+          if (vmp) x[e] += vmp[d0 + e];
+        }
+        uint2 w;
+        w.x = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[0]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[1]) << 16);
+        w.y = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[2]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[3]) << 16);
+        *reinterpret_cast<uint2*>(op + d0) = w;
+      }
+    if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * p.M + row] = m_run + log2f(l_tot);
+  }
+}
+
+template <int D, int NWAVES>
+static int launch_f16(const AttnParams& p, bool causal, bool kthread, bool out_bf16, bool v_bf16, hipStream_t st) {
+  const size_t smem = 2 * 64 * D + 2 * 64 * D * 2;
+  const dim3 grid(p.nqb * p.Hq * p.B), block(NWAVES * 64);
+#define SAGE_LAUNCH(C, K, O, V)                                                                          \
+  do {                                                                                                   \
+    auto kern = attn_i8_f16_kernel<D, NWAVES, C, K, O, V>;                                              \
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                 \
+  } while (0)
+#define SAGE_BY_V(C, K, O) do { if (v_bf16) SAGE_LAUNCH(C, K, O, true); else SAGE_LAUNCH(C, K, O, false); } while (0)
+#define SAGE_BY_O(C, K) do { if (out_bf16) SAGE_BY_V(C, K, true); else SAGE_BY_V(C, K, false); } while (0)
+#define SAGE_BY_K(C) do { if (kthread) SAGE_BY_O(C, true); else SAGE_BY_O(C, false); } while (0)
+  if (causal) SAGE_BY_K(true); else SAGE_BY_K(false);
+#undef SAGE_BY_K
+#undef SAGE_BY_O
+#undef SAGE_BY_V
+#undef SAGE_LAUNCH
+  return launch_status();
+}
+
+static bool t_ok(const sage_tensor* t, int align_elems) {
+  return t && t->data && aligned16(t->data) && t->stride_b % align_elems == 0 && t->stride_h % align_elems == 0 &&
+         t->stride_n % align_elems == 0;
+}
+
+int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
+
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" int sage_set_tuning(int key, int value) {
+  if (key == SAGE_TUNE_NWAVES) {
+    if (value != 0 && value != 4 && value != 8) return SAGE_ERR_INVALID_ARGUMENT;
+    g_nwaves_override = value;
+    return SAGE_OK;
+  }
+  return SAGE_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int sage_attn_qk_int8_pv_f16(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, int v_dtype,
+                                        const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                        const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D,
+                                        int is_causal, int qk_gran, int blkq, int warpq, float sm_scale,
+                                        int logit_mult_is_one, sage_stream_t stream) {
+  if (!t_ok(q8, 16) || !t_ok(k8, 16) || !t_ok(v, 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
+  if (B <= 0 || Hq <= 0 || Hk <= 0 || M <= 0 || N <= 0 || Hq % Hk != 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if ((v_dtype != SAGE_F16 && v_dtype != SAGE_BF16) || (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (qk_gran < SAGE_GRAN_PER_BLOCK || qk_gran > SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
+  if (blkq != 64 && blkq != 128) return SAGE_ERR_INVALID_ARGUMENT;
+  if (qk_gran == SAGE_GRAN_PER_BLOCK) warpq = blkq;
+  if ((warpq != 16 && warpq != 32 && warpq != 64 && warpq != 128) || blkq % warpq != 0) return SAGE_ERR_INVALID_ARGUMENT;
+  AttnParams p;
+  p.q = (const int8_t*)q8->data; p.qsb = q8->stride_b; p.qsh = q8->stride_h; p.qsn = q8->stride_n;
+  p.k = (const int8_t*)k8->data; p.ksb = k8->stride_b; p.ksh = k8->stride_h; p.ksn = k8->stride_n;
+  p.v = (const uint8_t*)v->data; p.vsb = v->stride_b; p.vsh = v->stride_h; p.vsn = v->stride_n;
+  p.o = (uint16_t*)o->data; p.osb = o->stride_b; p.osh = o->stride_h; p.osn = o->stride_n;
+  p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = nullptr; p.v_mean = v_mean; p.lse = lse;
+  p.B = B; p.Hq = Hq; p.Hk = Hk; p.M = M; p.N = N;
+  const int nblkq = (M + blkq - 1) / blkq;
+  p.gq = qk_gran == SAGE_GRAN_PER_BLOCK ? nblkq : qk_gran == SAGE_GRAN_PER_WARP ? nblkq * (blkq / warpq) : nblkq * (blkq / warpq) * 8;
+  const int nblkk = (N + 63) / 64;
+  p.gk = qk_gran == SAGE_GRAN_PER_THREAD ? nblkk * 4 : nblkk;
+  p.qgran = qk_gran; p.blkq = blkq; p.warpq = warpq;
+  p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
+  const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD;
+  int nw = g_nwaves_override ? g_nwaves_override : 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (nw == 8) {
+    p.nqb = (M + 255) / 256;
+    return D == 64 ? launch_f16<64, 8>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st)
+                   : launch_f16<128, 8>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st);
+  }
+  p.nqb = (M + 127) / 128;
+  return D == 64 ? launch_f16<64, 4>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st)
+                 : launch_f16<128, 4>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st);
+}

@@ -1,0 +1,82 @@
+// Small helpers of the hot path: library info, LSE finishing (core.py:651) and the ring-attention
+// state merge (new component; rule in SURVEY.md section 5).  Elementwise, HBM-bound.
+#include "sage_common.h"
+
+namespace sage {
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void merge_states_kernel(float* __restrict__ o_acc, float* __restrict__ lse_acc,
+                                                           const uint16_t* __restrict__ o_blk,
+                                                           const float* __restrict__ lse_blk, int64_t rows, int D) {
+  // one thread per 8 output elements; D/8 threads per row
+  const int tpr = D / 8;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = gid / tpr;
+  const int c = (int)(gid % tpr);
+  if (row >= rows) return;
+  const float la = lse_acc[row], lb = lse_blk[row];
+  const float mx = fmaxf(la, lb);
+  // logaddexp; la = -inf (empty accumulator) gives wa = 0, wb = 1
+  const float ea = (la == -INFINITY) ? 0.f : __expf(la - mx), eb = (lb == -INFINITY) ? 0.f : __expf(lb - mx);
+  const float sum = ea + eb;
+  const float lse = (sum > 0.f) ? mx + __logf(sum) : -INFINITY;
+  const float wa = (sum > 0.f) ? ea / sum : 0.f, wb = (sum > 0.f) ? eb / sum : 0.f;
+  float* oa = o_acc + row * D + c * 8;
+  float fb[8];
+  unpack8<BF16>(*reinterpret_cast<const uint4*>(o_blk + row * D + c * 8), fb);
+  float4 a0 = *reinterpret_cast<float4*>(oa), a1 = *reinterpret_cast<float4*>(oa + 4);
+  a0.x = a0.x * wa + fb[0] * wb; a0.y = a0.y * wa + fb[1] * wb; a0.z = a0.z * wa + fb[2] * wb; a0.w = a0.w * wa + fb[3] * wb;
+  a1.x = a1.x * wa + fb[4] * wb; a1.y = a1.y * wa + fb[5] * wb; a1.z = a1.z * wa + fb[6] * wb; a1.w = a1.w * wa + fb[7] * wb;
+  *reinterpret_cast<float4*>(oa) = a0;
+  *reinterpret_cast<float4*>(oa + 4) = a1;
+  __syncthreads();  // all threads of a row have read lse_acc[row] (rows never straddle a block: 256 % tpr == 0)
+  if (c == 0) lse_acc[row] = lse;
+}
+
+__global__ __launch_bounds__(256) void finish_lse_kernel(const float* __restrict__ lse2, const float* __restrict__ corr,
+                                                         float sm_scale, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = lse2[i] / 1.44269504f;  // core.py:651
+  if (corr) v += corr[i] * sm_scale;
+  out[i] = v;
+}
+
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" int sage_abi_version(void) { return SAGEATTN_HIP_ABI_VERSION; }
+extern "C" const char* sage_target_arch(void) { return "gfx950"; }
+extern "C" const char* sage_status_string(int status) {
+  switch (status) {
+    case SAGE_OK: return "ok";
+    case SAGE_ERR_INVALID_ARGUMENT: return "invalid argument (null/unaligned pointer, bad enum or inconsistent sizes)";
+    case SAGE_ERR_UNSUPPORTED_HEAD_DIM: return "unsupported head_dim (must be 64 or 128 after padding)";
+    case SAGE_ERR_UNSUPPORTED: return "configuration not supported by this build";
+    case SAGE_ERR_TOO_LARGE: return "tensor slice too large";
+    case SAGE_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int sage_merge_attn_states(float* o_acc, float* lse_acc, const void* o_blk, int o_dtype, const float* lse_blk,
+                                      int64_t rows, int D, sage_stream_t stream) {
+  if (!o_acc || !lse_acc || !o_blk || !lse_blk || rows <= 0 || !aligned16(o_acc) || !aligned16(o_blk)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int64_t threads = rows * (D / 8);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (o_dtype == SAGE_BF16)
+    hipLaunchKernelGGL((merge_states_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, o_acc, lse_acc, (const uint16_t*)o_blk, lse_blk, rows, D);
+  else
+    hipLaunchKernelGGL((merge_states_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, o_acc, lse_acc, (const uint16_t*)o_blk, lse_blk, rows, D);
+  return launch_status();
+}
+
+extern "C" int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out, int64_t n,
+                               sage_stream_t stream) {
+  if (!lse2 || !lse_out || n <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(finish_lse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lse2, corr, sm_scale, lse_out, n);
+  return launch_status();
+}

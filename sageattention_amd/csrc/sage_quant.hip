@@ -1,0 +1,311 @@
+// HBM-bound pre-pass kernels of the SageAttention hot path for gfx950:
+//   K0  k_mean            (replaces torch k.mean at sageattention/core.py:612)
+//   K1  quant_qk_int8     (replaces QuantInt8Kernel csrc/fused/fused.cu:64-198 and the Triton
+//                          quantizers sageattention/triton/quant_per_{block,thread}.py)
+//   K2  sub_mean_f16      (replaces SubMeanKernel csrc/fused/fused.cu:200-260)
+// Roofline: HBM. Algorithmic traffic per element: 2 B read + 1 B written (K1), 2 B read (K0).
+// Every thread moves 16 B per load (8 fp16/bf16), the widest coalesced access on CDNA4.
+// Compiled with -ffp-contract=off: the integer outputs must match the oracle bit for bit.
+#include "sage_common.h"
+
+namespace sage {
+
+// ------------------------------------------------------------------------------------------------
+// K0: k_mean, deterministic two-pass reduction
+// ------------------------------------------------------------------------------------------------
+constexpr int KMEAN_ROWS = 256;  // rows per workgroup in pass 1
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void k_mean_partial_kernel(const uint16_t* __restrict__ k, int64_t sb, int64_t sh,
+                                                             int64_t sn, int N, float* __restrict__ part, int S) {
+  constexpr int TPR = D / 8;       // threads per row
+  constexpr int RPP = 256 / TPR;   // rows per pass
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  const uint16_t* base = k + b * sb + h * sh + tc * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int r0 = s * KMEAN_ROWS;
+#pragma unroll 4
+  for (int i = 0; i < KMEAN_ROWS / RPP; ++i) {
+    const int row = r0 + i * RPP + tr;
+    if (row < N) {
+      const uint4 u = *reinterpret_cast<const uint4*>(base + (int64_t)row * sn);
+      float f[8];
+      unpack8<BF16>(u, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+  }
+  __shared__ float red[RPP][D + 1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tr][tc * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float sum = 0.f;
+    for (int r = 0; r < RPP; ++r) sum += red[r][threadIdx.x];  // fixed order
+    part[(((int64_t)b * gridDim.y + h) * S + s) * D + threadIdx.x] = sum;
+  }
+}
+
+template <bool BF16>
+__global__ void k_mean_final_kernel(const float* __restrict__ part, int S, int D, int N, uint16_t* __restrict__ km) {
+  const int64_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) sum += part[(bh * S + s) * D + d];
+  km[bh * D + d] = f32_to_elem_bits<BF16>(sum / (float)N);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: INT8 quantizer, all granularities
+// ------------------------------------------------------------------------------------------------
+struct QuantParams {
+  const uint16_t* x;
+  int64_t xsb, xsh, xsn;
+  const uint16_t* mean;  // [B,H,D] or null
+  int8_t* out;
+  int64_t osb, osh, osn;
+  float* scale;  // [B,H,G]
+  const uint16_t* dot_vec;  // [B,H/dot_group,D] or null
+  float* dot_out;           // [B,H,N]
+  int dot_group;
+  int N, G;          // rows, scales per (b,h)
+  int gran, is_key;  // sage_qk_gran, K-side grouping of per_thread
+  int warp;          // rows per warp group
+  float mult;
+  int rounding;
+};
+
+__device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp) {
+  // group-id maps: per_block: all rows of the workgroup; per_warp: lr/warp; per_thread:
+  // triton/quant_per_thread.py:27-36 (Q: r%8) and :73-80 (K: (r%8)/2).
+  if (gran == SAGE_GRAN_PER_BLOCK) return 0;
+  if (gran == SAGE_GRAN_PER_WARP) return lr / warp;
+  return is_key ? (lr / warp) * 4 + (lr % 8) / 2 : (lr / warp) * 8 + lr % 8;
+}
+
+template <int D, int BLK, bool BF16>
+__global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p) {
+  constexpr int TPR = D / 8;
+  constexpr int RPP = 256 / TPR;
+  constexpr int NP = BLK / RPP;
+  static_assert(NP >= 1, "block too small");
+  const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int H = gridDim.y;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+
+  __shared__ unsigned int gmax[64];
+  if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
+
+  float mean_f[8];
+  if (p.mean) {
+    const uint4 um = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)b * H + h) * D + tc * 8);
+    unpack8<BF16>(um, mean_f);
+  }
+  float dvec[8];
+  if (p.dot_vec) {
+    const int Hk = H / p.dot_group;
+    const uint4 ud = *reinterpret_cast<const uint4*>(p.dot_vec + ((int64_t)b * Hk + h / p.dot_group) * D + tc * 8);
+    unpack8<BF16>(ud, dvec);
+  }
+
+  const uint16_t* xbase = p.x + b * p.xsb + h * p.xsh + tc * 8;
+  float xf[NP][8];
+  uint4 raw[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int row = blk * BLK + i * RPP + tr;
+    raw[i] = make_uint4(0, 0, 0, 0);
+    if (row < p.N) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xsn);
+  }
+  __syncthreads();  // gmax zeroed
+
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int lr = i * RPP + tr;
+    const int row = blk * BLK + lr;
+    const bool valid = row < p.N;
+    unpack8<BF16>(raw[i], xf[i]);
+    if (p.dot_vec) {
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += xf[i][j] * dvec[j];
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) dot += __shfl_xor(dot, o);
+      if (tc == 0 && valid) p.dot_out[((int64_t)b * H + h) * p.N + row] = dot;
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = xf[i][j];
+      if (p.mean) {
+        v = v - mean_f[j];
+        if (p.rounding == SAGE_ROUND_TRITON) v = round_to_elem<BF16>(v);  // torch `k - km` in the input dtype
+      }
+      v = v * p.mult;
+      if (!valid) v = 0.f;
+      xf[i][j] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (tc == 0) atomicMax(&gmax[group_of_row(lr, p.gran, p.is_key, p.warp)], __float_as_uint(amax));
+  }
+  __syncthreads();
+
+  const int groups_per_blk = p.gran == SAGE_GRAN_PER_BLOCK ? 1
+                             : p.gran == SAGE_GRAN_PER_WARP ? BLK / p.warp
+                                                            : (BLK / p.warp) * (p.is_key ? 4 : 8);
+  const float eps = (p.gran == SAGE_GRAN_PER_THREAD) ? 0.0000001f : 0.f;
+  if (threadIdx.x < groups_per_blk) {
+    const float a = __uint_as_float(gmax[threadIdx.x]);
+    const float sc = (p.rounding == SAGE_ROUND_TRITON) ? a / 127.f + eps : fmaxf(a, 0.0000001f) / 127.f;
+    p.scale[((int64_t)b * H + h) * p.G + blk * groups_per_blk + threadIdx.x] = sc;
+  }
+
+  int8_t* obase = p.out + b * p.osb + h * p.osh + tc * 8;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int lr = i * RPP + tr;
+    const int row = blk * BLK + lr;
+    const float a = __uint_as_float(gmax[group_of_row(lr, p.gran, p.is_key, p.warp)]);
+    int q[8];
+    if (p.rounding == SAGE_ROUND_TRITON) {
+      const float sc = a / 127.f + eps;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = xf[i][j] / sc;  // IEEE division (quant_per_block.py:42)
+        y = y + (y >= 0.f ? 0.5f : -0.5f);
+        q[j] = (int)y;  // truncation, as tl `.to(int8)`
+      }
+    } else {
+      const float inv = 127.f / fmaxf(a, 0.0000001f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = (int)rintf(xf[i][j] * inv);  // cvt.rni (fused.cu:176-181)
+    }
+    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w0 |= (uint32_t)(min(max(q[j], -128), 127) & 0xff) << (8 * j);
+      w1 |= (uint32_t)(min(max(q[4 + j], -128), 127) & 0xff) << (8 * j);
+    }
+    if (row < p.N) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.osn) = make_uint2(w0, w1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: sub_mean_f16
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void sub_mean_f16_kernel(const uint16_t* __restrict__ v, int64_t sb, int64_t sh,
+                                                           int64_t sn, const uint16_t* __restrict__ vm,
+                                                           uint16_t* __restrict__ out, int64_t ob, int64_t oh,
+                                                           int64_t on, int N, int D) {
+  const int TPR = D / 8, RPP = 256 / TPR;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  const int row = blockIdx.x * RPP + tr;
+  if (row >= N) return;
+  float m[8], x[8];
+  unpack8<BF16>(*reinterpret_cast<const uint4*>(vm + ((int64_t)b * H + h) * D + tc * 8), m);
+  unpack8<BF16>(*reinterpret_cast<const uint4*>(v + b * sb + h * sh + (int64_t)row * sn + tc * 8), x);
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // packed subtraction in the input dtype (fused.cu:233), then fp16 (:235-238)
+    const float lo = round_to_elem<BF16>(x[2 * j] - m[2 * j]);
+    const float hi = round_to_elem<BF16>(x[2 * j + 1] - m[2 * j + 1]);
+    w[j] = (uint32_t)f32_to_elem_bits<false>(lo) | ((uint32_t)f32_to_elem_bits<false>(hi) << 16);
+  }
+  *reinterpret_cast<uint4*>(out + b * ob + h * oh + (int64_t)row * on + tc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+static bool tensor_ok(const sage_tensor* t, int align_elems) {
+  return t && t->data && aligned16(t->data) && t->stride_b % align_elems == 0 && t->stride_h % align_elems == 0 &&
+         t->stride_n % align_elems == 0;
+}
+
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" size_t sage_k_mean_workspace_bytes(int B, int H, int N, int D) {
+  const size_t S = (size_t)(N + KMEAN_ROWS - 1) / KMEAN_ROWS;
+  return (size_t)B * H * S * D * sizeof(float);
+}
+
+extern "C" int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N, int D, void* km, void* workspace,
+                           sage_stream_t stream) {
+  if (!tensor_ok(k, 8) || !km || !workspace || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(S, H, B);
+  const uint16_t* kp = (const uint16_t*)k->data;
+  float* ws = (float*)workspace;
+#define LAUNCH(DD, BF)                                                                                         \
+  hipLaunchKernelGGL((k_mean_partial_kernel<DD, BF>), grid, dim3(256), 0, st, kp, k->stride_b, k->stride_h, \
+                     k->stride_n, N, ws, S)
+  if (D == 64) { if (dtype == SAGE_BF16) LAUNCH(64, true); else LAUNCH(64, false); }
+  else { if (dtype == SAGE_BF16) LAUNCH(128, true); else LAUNCH(128, false); }
+#undef LAUNCH
+  if (dtype == SAGE_BF16)
+    hipLaunchKernelGGL((k_mean_final_kernel<true>), dim3(B * H), dim3(128), 0, st, ws, S, D, N, (uint16_t*)km);
+  else
+    hipLaunchKernelGGL((k_mean_final_kernel<false>), dim3(B * H), dim3(128), 0, st, ws, S, D, N, (uint16_t*)km);
+  return launch_status();
+}
+
+extern "C" int sage_quant_qk_int8(const sage_tensor* x, int dtype, int B, int H, int N, int D, const void* mean,
+                                  const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
+                                  float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
+                                  sage_stream_t stream) {
+  if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !scale || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  if (gran < SAGE_GRAN_PER_BLOCK || gran > SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
+  if (rounding != SAGE_ROUND_TRITON && rounding != SAGE_ROUND_CUDA) return SAGE_ERR_INVALID_ARGUMENT;
+  if (blk != 64 && blk != 128) return SAGE_ERR_INVALID_ARGUMENT;
+  if (gran == SAGE_GRAN_PER_BLOCK) warp = blk;
+  if ((warp != 16 && warp != 32 && warp != 64 && warp != 128) || blk % warp != 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (mean && !aligned16(mean)) return SAGE_ERR_INVALID_ARGUMENT;
+  if ((lse_dot_vec != nullptr) != (lse_dot != nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (lse_dot_vec && (dot_group <= 0 || H % dot_group != 0 || !aligned16(lse_dot_vec))) return SAGE_ERR_INVALID_ARGUMENT;
+  const int nblk = (N + blk - 1) / blk;
+  const int gpb = gran == SAGE_GRAN_PER_BLOCK ? 1 : gran == SAGE_GRAN_PER_WARP ? blk / warp : (blk / warp) * (is_key ? 4 : 8);
+  if (gpb > 64) return SAGE_ERR_INVALID_ARGUMENT;
+  QuantParams p;
+  p.x = (const uint16_t*)x->data; p.xsb = x->stride_b; p.xsh = x->stride_h; p.xsn = x->stride_n;
+  p.mean = (const uint16_t*)mean;
+  p.out = (int8_t*)out->data; p.osb = out->stride_b; p.osh = out->stride_h; p.osn = out->stride_n;
+  p.scale = scale; p.dot_vec = (const uint16_t*)lse_dot_vec; p.dot_out = lse_dot; p.dot_group = dot_group > 0 ? dot_group : 1;
+  p.N = N; p.G = nblk * gpb; p.gran = gran; p.is_key = is_key ? 1 : 0; p.warp = warp; p.mult = mult; p.rounding = rounding;
+  dim3 grid(nblk, H, B);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(DD, BL, BF) hipLaunchKernelGGL((quant_qk_int8_kernel<DD, BL, BF>), grid, dim3(256), 0, st, p)
+#define BY_DT(DD, BL) do { if (dtype == SAGE_BF16) LAUNCH(DD, BL, true); else LAUNCH(DD, BL, false); } while (0)
+  if (D == 64) { if (blk == 64) BY_DT(64, 64); else BY_DT(64, 128); }
+  else { if (blk == 64) BY_DT(128, 64); else BY_DT(128, 128); }
+#undef BY_DT
+#undef LAUNCH
+  return launch_status();
+}
+
+extern "C" int sage_sub_mean_f16(const sage_tensor* v, int dtype, int B, int H, int N, int D, const void* vm,
+                                 const sage_tensor* out, sage_stream_t stream) {
+  if (!tensor_ok(v, 8) || !tensor_ok(out, 8) || !vm || !aligned16(vm) || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int RPP = 256 / (D / 8);
+  dim3 grid((N + RPP - 1) / RPP, H, B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SAGE_BF16)
+    hipLaunchKernelGGL((sub_mean_f16_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)v->data, v->stride_b, v->stride_h,
+                       v->stride_n, (const uint16_t*)vm, (uint16_t*)out->data, out->stride_b, out->stride_h, out->stride_n, N, D);
+  else
+    hipLaunchKernelGGL((sub_mean_f16_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)v->data, v->stride_b, v->stride_h,
+                       v->stride_n, (const uint16_t*)vm, (uint16_t*)out->data, out->stride_b, out->stride_h, out->stride_n, N, D);
+  return launch_status();
+}

@@ -1,0 +1,106 @@
+"""Host-side mirror of ``sageattention/quant.py`` (reference) on top of the gfx950 C-ABI library.
+
+Same function names, argument meaning and returned shapes as the reference
+(``per_block_int8`` quant.py:23, ``per_warp_int8`` :106, ``sub_mean`` :183, ``per_channel_fp8`` :225) plus
+``per_thread_int8`` (sageattention/triton/quant_per_thread.py:158) and ``k_mean`` (core.py:612)."""
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _km3(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torch.Tensor]:
+    """km arrives keepdim (core.py:612) or squeezed (quant.py:99); the C ABI wants [B,H,D] contiguous."""
+    if km is None:
+        return None
+    if km.dim() == 4:
+        km = km.squeeze(1) if tensor_layout == "NHD" else km.squeeze(2)
+    return km.contiguous()
+
+
+def _quant(x, tensor_layout, gran, is_key, blk, warp, mult, rounding, mean=None, dot_vec=None, dot_group=1):
+    B, H, N, D = L.dims(x, tensor_layout)
+    out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    nblk = (N + blk - 1) // blk
+    if gran == L.GRAN_PER_BLOCK:
+        G = nblk
+    elif gran == L.GRAN_PER_WARP:
+        G = nblk * (blk // warp)
+    else:
+        G = nblk * (blk // warp) * (4 if is_key else 8)
+    scale = torch.empty((B, H, G), dtype=torch.float32, device=x.device)
+    dot = torch.empty((B, H, N), dtype=torch.float32, device=x.device) if dot_vec is not None else None
+    xd, od = L.desc(x, tensor_layout), L.desc(out, tensor_layout)
+    st = L.lib().sage_quant_qk_int8(xd, L.dtype_code(x.dtype), B, H, N, D, L.ptr(mean), od, scale.data_ptr(),
+                                    gran, int(is_key), blk, warp, float(mult), rounding,
+                                    L.ptr(dot_vec), dot_group, L.ptr(dot), L.stream_ptr(x.device))
+    L.check(st, "sage_quant_qk_int8")
+    return out, scale, dot
+
+
+def k_mean(k: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
+    """``k.mean(dim=seq)`` of core.py:612 as one deterministic HIP reduction; returns [B,Hk,D] in k's dtype."""
+    B, H, N, D = L.dims(k, tensor_layout)
+    lib = L.lib()
+    ws = torch.empty(max(1, lib.sage_k_mean_workspace_bytes(B, H, N, D) // 4), dtype=torch.float32, device=k.device)
+    km = torch.empty((B, H, D), dtype=k.dtype, device=k.device)
+    L.check(lib.sage_k_mean(L.desc(k, tensor_layout), L.dtype_code(k.dtype), B, H, N, D, km.data_ptr(), ws.data_ptr(),
+                            L.stream_ptr(k.device)), "sage_k_mean")
+    return km
+
+
+def per_block_int8(q, k, km=None, BLKQ=128, BLKK=64, sm_scale=None, tensor_layout="HND", rounding="cuda"):
+    """quant.py:23-104.  ``rounding="triton"`` gives the numerics of triton/quant_per_block.py:48-101."""
+    D = q.size(-1)
+    if sm_scale is None:
+        sm_scale = D ** -0.5
+    rnd = L.ROUND_CUDA if rounding == "cuda" else L.ROUND_TRITON
+    q8, qs, _ = _quant(q, tensor_layout, L.GRAN_PER_BLOCK, False, BLKQ, BLKQ, sm_scale * 1.44269504, rnd)
+    k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, BLKK, BLKK, 1.0, rnd, mean=_km3(km, tensor_layout))
+    return q8, qs, k8, ks
+
+
+def per_warp_int8(q, k, km=None, BLKQ=128, WARPQ=32, BLKK=64, tensor_layout="HND"):
+    """quant.py:106-181 (CUDA numerics: csrc/fused/fused.cu:685-768 for Q, :594-682 for K)."""
+    q8, qs, _ = _quant(q, tensor_layout, L.GRAN_PER_WARP, False, BLKQ, WARPQ, 1.0, L.ROUND_CUDA)
+    k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, BLKK, BLKK, 1.0, L.ROUND_CUDA, mean=_km3(km, tensor_layout))
+    return q8, qs, k8, ks
+
+
+def per_thread_int8(q, k, km=None, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64, sm_scale=None, tensor_layout="HND"):
+    """sageattention/triton/quant_per_thread.py:158-207 (sm_scale unused there as well, :187-188)."""
+    q8, qs, _ = _quant(q, tensor_layout, L.GRAN_PER_THREAD, False, BLKQ, WARPQ, 1.0, L.ROUND_TRITON)
+    k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, BLKK, WARPK, 1.0, L.ROUND_TRITON,
+                       mean=_km3(km, tensor_layout))
+    return q8, qs, k8, ks
+
+
+def sub_mean(v: torch.Tensor, tensor_layout: str = "HND"):
+    """quant.py:183-223: returns (fp16(v - mean_seq(v)), vm [B,H,D] in v's dtype)."""
+    B, H, N, D = L.dims(v, tensor_layout)
+    vm = k_mean(v, tensor_layout)
+    out = torch.empty(v.shape, dtype=torch.float16, device=v.device)
+    L.check(L.lib().sage_sub_mean_f16(L.desc(v, tensor_layout), L.dtype_code(v.dtype), B, H, N, D, vm.data_ptr(),
+                                      L.desc(out, tensor_layout), L.stream_ptr(v.device)), "sage_sub_mean_f16")
+    return out, vm
+
+
+def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = True):
+    """quant.py:225-322.  Returns (v_fp8 [B,H,D,ceil64(N)] (HND) / [B,D,H,ceil64(N)] (NHD) float8_e4m3fn (OCP, the
+    gfx950 MFMA format; the fork emits fnuz for gfx942), v_scale fp32 [B,H,D], vm fp32 [B,H,D] or None)."""
+    B, H, N, D = L.dims(v, tensor_layout)
+    npad = (N + 63) // 64 * 64
+    if tensor_layout == "HND":
+        v8 = torch.empty((B, H, D, npad), dtype=torch.float8_e4m3fn, device=v.device)
+        od = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(1), v8.stride(2))
+    else:
+        v8 = torch.empty((B, D, H, npad), dtype=torch.float8_e4m3fn, device=v.device)
+        od = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(2), v8.stride(1))
+    v_scale = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
+    vm = torch.empty((B, H, D), dtype=torch.float32, device=v.device) if smooth_v else None
+    lib = L.lib()
+    ws = torch.empty(max(1, lib.sage_quant_v_fp8_workspace_bytes(B, H, N, D) // 4), dtype=torch.float32, device=v.device)
+    L.check(lib.sage_quant_v_fp8(L.desc(v, tensor_layout), L.dtype_code(v.dtype), B, H, N, D, od, v_scale.data_ptr(),
+                                 L.ptr(vm), float(scale_max), ws.data_ptr(), L.stream_ptr(v.device)), "sage_quant_v_fp8")
+    return v8, v_scale, vm

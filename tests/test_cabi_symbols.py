@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/sageattn_hip.h declares.
+No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from sageattention_amd import _build
+    return _build.build()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sageattn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sage_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    names = _declared_symbols()
+    assert len(names) >= 13, names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sageattn_hip.h but not exported"
+
+
+def test_binding_covers_header(built_lib):
+    from sageattention_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+    l = _lib.lib()
+    assert l.sage_abi_version() == 1
+    assert l.sage_target_arch() == b"gfx950"
+    assert b"head_dim" in l.sage_status_string(-2)
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """Host-side validation returns status codes before anything touches a device."""
+    from sageattention_amd import _lib as L
+    l = L.lib()
+    t = L.SageTensor(None, 0, 0, 0)
+    assert l.sage_k_mean(t, 0, 1, 1, 1, 64, None, None, None) == -1
+    bad = L.SageTensor(16, 8, 8, 8)
+    assert l.sage_quant_qk_int8(bad, 0, 1, 1, 8, 96, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -2
+    assert l.sage_quant_qk_int8(bad, 7, 1, 1, 8, 64, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -1
+    assert l.sage_set_tuning(0, 5) == -1 and l.sage_set_tuning(0, 0) == 0
+
+
+def test_product_path_has_no_oracle_import():
+    """The shipped package must never import the oracle or fall back to CPU."""
+    pkg = os.path.join(ROOT, "sageattention_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+[^#\n]*oracle", src, flags=re.M), fn
+            assert "sage_oracle" not in src, fn
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from sageattention_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
