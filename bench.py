@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE metric: attention forward TFLOPS at head_dim=128, seqlen=8K (+ speedup vs FA2-ROCm).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|ring]
+
+A "step" is one pass of the whole hot path (K mean -> INT8 Q/K quantizers -> fused attention kernel) over one
+batch of synthetic (q,k,v) already resident in HBM.  TFLOPS = 4*B*H*M*N*D / t (/2 causal), the reference's own
+formula (bench/bench_baseline.py:31).  N=1 default workload: C3 = qk_int8_pv_fp16, (B,H,N,D)=(4,32,8192,128), the
+configuration the metric is quoted on.  N>1: ring sequence-parallel attention over RCCL on (1,32,65536,128)
+(BASELINE configs[4]), strong scaling.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P_MIX_TFLOPS = 3333.0  # 1/(0.5/5000 + 0.5/2500): int8 QK^T at 2x the fp16 PV MFMA rate
+
+WORKLOADS = {
+    # name: (B, H, N, D, causal, variant)
+    "c2": (4, 32, 2048, 64, False, "fp16"),
+    "c3": (4, 32, 8192, 128, False, "fp16"),
+    "c4": (4, 32, 16384, 128, True, "fp8"),
+    "ring": (1, 32, 65536, 128, False, "fp16"),
+}
+
+
+def flops(B, H, M, N, D, causal):
+    return 4.0 * B * H * M * N * D / (2.0 if causal else 1.0)
+
+
+def time_events(fn, steps, warmup):
+    """Average ms per call measured with HIP events on the current stream (the stream the kernels launch on)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(steps):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / steps
+
+
+def cpu_baseline(D, causal):
+    """The oracle (a CPU port of the same quantized algorithm) and torch SDPA fp32 on the host cores, on a bounded
+    sample of the workload (same head_dim, shorter sequence, fewer heads)."""
+    from oracle import sage_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, H, N = 1, 4, 4096
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, H, N, D, generator=g).to(torch.float16)
+    k = torch.randn(B, H, N, D, generator=g).to(torch.float16)
+    v = torch.randn(B, H, N, D, generator=g).to(torch.float16)
+    t0 = time.perf_counter()
+    O.sageattn_oracle(q, k, v, qk_quant_gran="per_thread", is_causal=causal)
+    t_port = time.perf_counter() - t0
+    qf, kf, vf = q.float(), k.float(), v.float()
+    t0 = time.perf_counter()
+    torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=causal)
+    t_sdpa = time.perf_counter() - t0
+    fl = flops(B, H, N, N, D, causal)
+    sample = f"(B,H,N,D)=({B},{H},{N},{D}) fp16 inputs, same head_dim, 1 pass"
+    return ({"value": round(fl / t_port / 1e12, 5), "unit": "TFLOPS", "cores": cores, "kind": "port", "sample": sample,
+             "seconds": round(t_port, 2)},
+            {"value": round(fl / t_sdpa / 1e12, 5), "unit": "TFLOPS", "cores": cores, "kind": "torch-sdpa-fp32",
+             "sample": sample, "seconds": round(t_sdpa, 2)})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
+    ap.add_argument("--gran", default="per_thread", choices=["per_warp", "per_thread"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fa2", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sageattention_amd as sa
+    from sageattention_amd import _lib as L, _qattn
+    from sageattention_amd import core as sacore
+
+    wl = args.workload or ("c3" if world == 1 else "ring")
+    B, H, N, D, causal, variant = WORKLOADS[wl]
+    torch.manual_seed(0)
+
+    if wl == "ring" and world > 1:
+        from sageattention_amd import ring
+        n_local = N // world
+        q = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
+        k = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
+        v = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
+
+        def step():
+            return ring.ring_sageattn(q, k, v, is_causal=causal)
+        parallelism = f"ring-sp{world}"
+    else:
+        q = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
+        k = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
+        v = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
+        entry = sa.sageattn_qk_int8_pv_fp16_cuda if variant == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+
+        def step():
+            return entry(q, k, v, is_causal=causal, qk_quant_gran=args.gran)
+        parallelism = "single"
+
+    # ---- the contract's timed region: W warmup, K steps, barrier + synchronize on both sides, max over ranks
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_flops = flops(B, H, N, N, D, causal)
+    value = total_flops / (ms_per_step * 1e-3) / 1e12
+
+    out = {
+        "metric": "attention fwd TFLOPS at head_dim=128 seqlen=8K (INT8 QK^T + FP16 PV, quantizers included)",
+        "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "int8+fp16" if variant == "fp16" else "int8+fp8", "data": "synthetic",
+        "config": {"workload": f"{wl}: qk_int8_pv_{variant} (B,H,N,D)=({B},{H},{N},{D}) causal={causal} "
+                               f"qk_quant_gran={args.gran}", "global_batch": B, "seq_len": N, "head_dim": D,
+                   "heads": H, "parallelism": parallelism},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- dominant kernel alone (pre-quantized inputs), HIP events on the launch stream
+        with torch.cuda.device(dev):
+            km = sa.quant.k_mean(k)
+            q8, qs, k8, ks, _ = sacore._quant_qk(q, k, km, "HND", args.gran, D ** -0.5, 32, False, H, H)
+            o = torch.empty_like(q)
+            code = L.GRAN_PER_THREAD if args.gran == "per_thread" else L.GRAN_PER_WARP
+            if variant == "fp16":
+                def kern():
+                    _qattn._attn_f16(q8, k8, v, o, qs, ks, None, 1, int(causal), code, D ** -0.5, 0)
+            else:
+                v8, vsc, _ = sa.quant.per_channel_fp8(v, smooth_v=False)
+
+                def kern():
+                    _qattn._attn_f8(q8, k8, v8, o, qs, ks, vsc, None, 1, int(causal), code, D ** -0.5, 0)
+            k_ms = time_events(kern, args.steps, args.warmup)
+            k_tflops = total_flops / (k_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": P_MIX_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(k_tflops / P_MIX_TFLOPS, 4), "traffic": None,
+                               "kernel": "attn_i8_f16_kernel" if variant == "fp16" else "attn_i8_f8_kernel",
+                               "kernel_ms": round(k_ms, 4), "flops_per_launch": total_flops}
+            pre_ms = time_events(lambda: sacore._quant_qk(q, k, sa.quant.k_mean(k), "HND", args.gran, D ** -0.5, 32,
+                                                          False, H, H), args.steps, args.warmup)
+            # quantizer pre-pass: algorithmic bytes = K read twice (mean, quant) + Q read once + int8 written
+            pre_bytes = (q.numel() * 2 + k.numel() * 2 * 2 + q.numel() + k.numel())
+            out["prepass"] = {"ms": round(pre_ms, 4), "GBps": round(pre_bytes / (pre_ms * 1e-3) / 1e9, 1),
+                              "bound": "hbm", "peak_GBps": 8000}
+            if not args.no_fa2:
+                try:
+                    from torch.nn.attention import SDPBackend, sdpa_kernel
+                    with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+                        fa_ms = time_events(lambda: torch.nn.functional.scaled_dot_product_attention(
+                            q, k, v, is_causal=causal), args.steps, args.warmup)
+                    fa_tflops = total_flops / (fa_ms * 1e-3) / 1e12
+                    out["fa2_rocm"] = {"tflops": round(fa_tflops, 2), "ms": round(fa_ms, 4),
+                                       "speedup_end_to_end": round(value / fa_tflops, 3),
+                                       "speedup_kernel_only": round(k_tflops / fa_tflops, 3)}
+                except Exception as e:  # comparator only
+                    out["fa2_rocm"] = {"error": repr(e)[:200]}
+        if not args.no_cpu_baseline:
+            port, sdpa = cpu_baseline(D, causal)
+            out["cpu_baseline"] = port
+            out["cpu_sdpa"] = sdpa
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
