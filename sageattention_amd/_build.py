@@ -13,7 +13,7 @@ ARCH = "gfx950"
 # (source, extra flags).  The quantizers need exact IEEE semantics (bit-exact vs the oracle).
 SOURCES = [
     ("sage_quant.hip", ["-ffp-contract=off"]),
-    ("sage_attn.hip", []),
+    ("sage_attn.hip", ["-fno-slp-vectorize"]),  # packed f32 VALU is slower beside MFMAs
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
 ]

@@ -17,6 +17,7 @@
 //
 // Roofline: MFMA (4*M*N*D flop per (b,h); half int8 at 2x the fp16 rate), VALU/exp2 co-limited.
 // Algorithmic HBM bytes per (b,h): M*D (Q) + N*D (K) + 2*N*D (V fp16) + 2*M*D (O) + scales.
+#include <type_traits>
 #include "sage_common.h"
 
 namespace sage {
@@ -186,105 +187,146 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc_o[dt][e] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
+  // The int32 accumulator of S^T starts at the BIT PATTERN of 1.5*2^23: for |S| < 2^22 (|S| <= 128*127^2) the
+  // accumulated integer, reinterpreted as fp32, IS the float 12582912 + S exactly, so the logit needs no
+  // v_cvt_f32_i32: t - m = fma(as_float(acc), scale, -(12582912*scale + m)).
+  constexpr int kBiasI = 0x4B400000;
+  constexpr float kBiasF = 12582912.0f;
+  v16i bias;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bias[e] = kBiasI;
 
   load_tile(0);
   store_tile(0);
   __syncthreads();
 
-  for (int j = 0; j < ntiles; ++j) {
-    const int buf = j & 1;
+  // One KV tile for this wave.  MASKED: tiles crossing the causal diagonal or the end of the sequence.
+  auto tile = [&](const int j, const int buf, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int n0 = j << 6;
-    if (j + 1 < ntiles) load_tile(j + 1);
-
-    if (j < wave_tiles) {
-      // ---- S^T = K . Q^T  (2 tiles of 32 keys x 32 query rows)
-      v16i s_acc[2];
+    // ---- S^T = K . Q^T  (2 tiles of 32 keys x 32 query rows)
+    v16i s_acc[2];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s_acc[mt][e] = 0;
+      for (int ks = 0; ks < KS; ++ks) {
+        const v4i a = *reinterpret_cast<const v4i*>(k_lds + buf * KBYTES + mt * 32 * D + k_rd[ks]);
+        s_acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : s_acc[mt], 0, 0, 0);
+      }
+    }
+    // ---- dequantisation scales of this tile
+    float sc0, sc1;
+    if constexpr (KTHREAD) {  // …sm80.cu:131: 4 scales per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
+      sc0 = qsc * ksp[j * 4 + 2 * hh];
+      sc1 = qsc * ksp[j * 4 + 2 * hh + 1];
+    } else {
+      sc0 = sc1 = qsc * ksp[j];
+    }
+    if constexpr (MASKED) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const v4i a = *reinterpret_cast<const v4i*>(k_lds + buf * KBYTES + mt * 32 * D + k_rd[ks]);
-          s_acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s_acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const bool bad = (kv >= p.N) || (CAUSAL && kv > row);
+          s_acc[mt][e] = bad ? (kBiasI - (1 << 22)) : s_acc[mt][e];  // below every real score: loses the max
         }
+    }
+    // ---- row max on the raw integers (scales are positive): v_max3_i32, then one convert per scale group
+    int mxa = s_acc[0][0], mxb = s_acc[0][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (e & 2) mxb = max(mxb, s_acc[mt][e]); else mxa = max(mxa, s_acc[mt][e]);
       }
-      // ---- dequantisation scales of this tile
-      float sc0, sc1;
-      if constexpr (KTHREAD) {  // …sm80.cu:131: 4 scales per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
-        sc0 = qsc * ksp[j * 4 + 2 * hh];
-        sc1 = qsc * ksp[j * 4 + 2 * hh + 1];
-      } else {
-        sc0 = sc1 = qsc * ksp[j];
-      }
-      // ---- logits (base 2), masks
-      float t[2][16];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) t[mt][e] = (float)s_acc[mt][e] * ((e & 2) ? sc1 : sc0);
-      const bool need_mask = (n0 + 64 > p.N) || (CAUSAL && (n0 + 63 > q0));
-      if (need_mask) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            const bool bad = (kv >= p.N) || (CAUSAL && kv > row);
-            t[mt][e] = bad ? -INFINITY : t[mt][e];
-          }
-      }
-      // ---- online softmax (attn_utils.cuh:354-458), one query row per lane
-      float mx = t[0][0];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[mt][e]);
-      mx = swap_max(mx);
+    float mx;
+    if constexpr (KTHREAD) mx = fmaxf((float)(mxa - kBiasI) * sc0, (float)(mxb - kBiasI) * sc1);
+    else mx = (float)(max(mxa, mxb) - kBiasI) * sc0;
+    mx = swap_max(mx);
+    // ---- lazy rescale (attn_utils.cuh:354-458 rescales every tile; here only when some row's max grew by
+    //      more than kLazyThr, so p <= 2^kLazyThr, harmless in fp16/fp32; m_run stays exact for the LSE)
+    constexpr float kLazyThr = 6.0f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m_run + kLazyThr) != 0, 0)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
-      float psum = 0.f;
-      v8h pf[2][2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const float p0 = __builtin_amdgcn_exp2f(t[mt][8 * s + e] - m_new);
-            const float p1 = __builtin_amdgcn_exp2f(t[mt][8 * s + e + 1] - m_new);
-            psum += p0 + p1;
-            v2f pp = {p0, p1};
-            const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
-            pf[mt][s][e] = ph[0];
-            pf[mt][s][e + 1] = ph[1];
-          }
-      l_run = l_run * alpha + psum;
+      l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[dt][e] *= alpha;
-      // ---- O^T += V^T . P^T
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const char* base = v_lds + buf * VBYTES + (32 * mt + 16 * s) * (2 * D) + v_rd[dt];
-            const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) v4s_vs*)(base));
-            const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
-            v8h a;
-            a.s0123 = __builtin_bit_cast(v4h, lo);
-            a.s4567 = __builtin_bit_cast(v4h, hi);
-            acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[mt][s], acc_o[dt], 0, 0, 0);
-          }
     }
+    // ---- p = exp2(t - m), fp16 P^T fragments, fp32 row sum
+    const float c0 = __builtin_fmaf(-kBiasF, sc0, -m_run), c1 = __builtin_fmaf(-kBiasF, sc1, -m_run);
+    float psum0 = 0.f, psum1 = 0.f;
+    v8h pf[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const bool g1 = (e & 2) != 0;
+          float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s_acc[mt][8 * s + e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+          float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s_acc[mt][8 * s + e + 1]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+          if constexpr (MASKED) {
+            const int kv = n0 + 32 * mt + ((8 * s + e) & 3) + 8 * ((8 * s + e) >> 2) + 4 * hh;
+            p0 = ((kv >= p.N) || (CAUSAL && kv > row)) ? 0.f : p0;
+            p1 = ((kv + 1 >= p.N) || (CAUSAL && kv + 1 > row)) ? 0.f : p1;
+          }
+          psum0 += p0;
+          psum1 += p1;
+          v2f pp = {p0, p1};
+          const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
+          pf[mt][s][e] = ph[0];
+          pf[mt][s][e + 1] = ph[1];
+        }
+    l_run += psum0 + psum1;
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* base = v_lds + buf * VBYTES + (32 * mt + 16 * s) * (2 * D) + v_rd[dt];
+          const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4s_vs*)(base));
+          const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
+          v8h a;
+          a.s0123 = __builtin_bit_cast(v4h, lo);
+          a.s4567 = __builtin_bit_cast(v4h, hi);
+          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[mt][s], acc_o[dt], 0, 0, 0);
+        }
+  };
 
+  // Three straight-line loops (the O accumulator must not flow through merge points in the hot loop):
+  //   [0, n_plain)            tiles fully inside the causal triangle and the sequence: no mask code
+  //   [n_plain, wave_tiles)   tiles crossing the diagonal / the end of the sequence
+  //   [wave_tiles, ntiles)    causal only: this wave is done but still stages tiles for its workgroup
+  // Every wave executes exactly ntiles barriers.
+  int n_plain = wave_tiles;
+  if (p.N & 63) n_plain = min(n_plain, p.N >> 6);
+  if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
+  int j = 0;
+  for (; j < n_plain; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < ntiles) load_tile(j + 1);
+    tile(j, buf, std::false_type{});
     if (j + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  for (; j < wave_tiles; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < ntiles) load_tile(j + 1);
+    tile(j, buf, std::true_type{});
+    if (j + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  for (; j < ntiles; ++j) {
+    if (j + 1 < ntiles) { load_tile(j + 1); store_tile((j & 1) ^ 1); }
     __syncthreads();
   }
 
@@ -293,23 +335,27 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   const float inv = 1.0f / l_tot;
   if (row < p.M) {
     uint16_t* op = p.o + b * p.osb + h * p.osh + (int64_t)row * p.osn;
-    const float* vmp = p.v_mean ? p.v_mean + ((int64_t)b * p.Hk + hk) * D : nullptr;
+    auto store_rows = [&](auto has_vm) __attribute__((always_inline)) {
+      const float* vmp = p.v_mean + ((int64_t)b * p.Hk + hk) * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int d0 = 32 * dt + 8 * g4 + 4 * hh;
-        float x[4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+          float x[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          x[e] = acc_o[dt][4 * g4 + e] * inv;
-          if (vmp) x[e] += vmp[d0 + e];
+          for (int e = 0; e < 4; ++e) x[e] = acc_o[dt][4 * g4 + e] * inv;
+          if constexpr (decltype(has_vm)::value) {
+            const float4 vmv = *reinterpret_cast<const float4*>(vmp + d0);
+            x[0] += vmv.x; x[1] += vmv.y; x[2] += vmv.z; x[3] += vmv.w;
+          }
+          uint2 w;
+          w.x = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[0]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[1]) << 16);
+          w.y = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[2]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[3]) << 16);
+          *reinterpret_cast<uint2*>(op + d0) = w;
         }
-        uint2 w;
-        w.x = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[0]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[1]) << 16);
-        w.y = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[2]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[3]) << 16);
-        *reinterpret_cast<uint2*>(op + d0) = w;
-      }
+    };
+    if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
     if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * p.M + row] = m_run + log2f(l_tot);
   }
 }

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Launch the attention kernel alone a few times (for rocprofv3).  usage: run_attn.py [workload] [iters] [nwaves]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sageattention_amd as sa
+from sageattention_amd import _lib as L, _qattn, core
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+nw = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False),
+                      "c3c": (4, 32, 8192, 128, True), "c2c": (4, 32, 2048, 64, True)}[wl]
+L.lib().sage_set_tuning(0, nw)
+torch.manual_seed(0)
+q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+km = sa.quant.k_mean(k)
+q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
+o = torch.empty_like(q)
+for _ in range(iters):
+    _qattn._attn_f16(q8, k8, v, o, qs, ks, None, 1, int(causal), 3, D ** -0.5, 0)
+torch.cuda.synchronize()
+print("done", wl, iters)
