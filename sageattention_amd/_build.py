@@ -27,6 +27,27 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(out: str, extra_flags, verbose: bool = False) -> str:
+    """Timing-only variant build (ablations, A/B): separate objects, separate output library."""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="sage_variant_")
+    objs, procs = [], []
+    for src, extra in SOURCES:
+        o = os.path.join(tmp, src.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [HIPCC] + COMMON + extra + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, pr in procs:
+        o_, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{o_}")
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, "sage_common.h"), os.path.join(HERE, "..", "include", "sageattn_hip.h")]
     objs = []

@@ -62,6 +62,8 @@ def lib():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
+        if os.environ.get("SAGE_NWAVES"):  # tuning knob (speed only): waves per attention workgroup, 4 or 8
+            l.sage_set_tuning(0, int(os.environ["SAGE_NWAVES"]))
     return _lib
 
 

@@ -45,6 +45,14 @@ __device__ __forceinline__ float swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// 16 bytes per lane, global/buffer -> LDS without passing through VGPRs (buffer_load_dwordx4 ... lds).
+// `lds` must be wave-uniform; lane l lands at lds + 16*l.  Body hidden from the host pass (address-space cast).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
+#endif
+}
+
 template <int D>
 __device__ __forceinline__ int k_swz(int row) {
   // 16-B chunk XOR that makes the ds_read_b128 A-fragment reads conflict free
@@ -112,59 +120,82 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
     qsc = p.q_scale[((int64_t)b * p.Hq + h) * p.gq + qi] * p.logit_mult;
   }
   const float* ksp = p.k_scale + ((int64_t)b * p.Hk + hk) * p.gk;
+  const __amdgpu_buffer_rsrc_t ks_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ksp), 0, p.gk * 4, 0x00020000);
 
   // ---- tile range
   const int kv_end = CAUSAL ? min(p.N, (qb + 1) * QB) : p.N;
   const int ntiles = (kv_end + 63) >> 6;
   const int wave_tiles = CAUSAL ? min(ntiles, ((q0 + 31) >> 6) + 1) : ntiles;
 
-  // ---- staging (global -> regs -> LDS)
+  // ---- staging (global -> regs -> LDS).  Raw buffer loads: the descriptor holds the (b, h_kv) slice, the
+  //      per-thread byte offset is constant for the whole kernel and the tile advance is a scalar offset, so a
+  //      tile costs no address VALU; rows >= N fall outside num_records and read as ZERO (V rows beyond the
+  //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
   const int8_t* kg = p.k + b * p.ksb + hk * p.ksh;
   const uint8_t* vg = p.v + (b * p.vsb + hk * p.vsh) * 2;
-  uint4 kreg[KC], vreg[VC];
-  auto load_tile = [&](int j) {
-    const int n0 = j << 6;
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t*>(kg), 0, (int)((int64_t)(p.N - 1) * p.ksn + D), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(vg), 0, (int)(((int64_t)(p.N - 1) * p.vsn + D) * 2), 0x00020000);
+  const int k_tile_stride = 64 * (int)p.ksn, v_tile_stride = 128 * (int)p.vsn;  // bytes per 64 rows
+  // LDS-DMA (buffer_load ... lds): a wave instruction writes 64 x 16 B = 1 KiB of LDS LINEARLY (wave-uniform
+  // base + 16*lane), so the bank swizzle of the tile image is applied to the per-lane SOURCE offset instead:
+  // LDS chunk position c of a tile holds global chunk (row(c), pos(c) ^ swizzle(row)).  No VGPR staging, no
+  // ds_write, and the copy has a whole iteration to land (it is drained by the vmcnt(0) of the next barrier).
+  // bf16 V needs the fp16 conversion (core.py:633) and keeps the register path.
+  constexpr bool V_DMA = !V_BF16;
+  int k_voff[KC], v_voff[VC];
 #pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      const int c = tid + i * T;
-      if (KC * T == 64 * KCH || c < 64 * KCH) {
-        const int kr = min(n0 + c / KCH, p.N - 1);  // clamped: masked in the softmax
-        kreg[i] = *reinterpret_cast<const uint4*>(kg + (int64_t)kr * p.ksn + (c % KCH) * 16);
-      }
-    }
+  for (int i = 0; i < KC; ++i) {
+    const int c = tid + i * T, kr = c / KCH, pos = c % KCH;
+    k_voff[i] = kr * (int)p.ksn + ((pos ^ k_swz<D>(kr)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < VC; ++i) {
+    const int c = tid + i * T, vr = c / VCH, pos = c % VCH;
+    const int cc = V_DMA ? ((((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3)) : pos;
+    v_voff[i] = (vr * (int)p.vsn + cc * 8) * 2;
+  }
+  typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+  u32x4 vreg[V_DMA ? 1 : VC];
+  int v_wr[V_DMA ? 1 : VC];
+  if constexpr (!V_DMA) {
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
-      const int c = tid + i * T;
-      const int vr = n0 + c / VCH;
-      vreg[i] = make_uint4(0, 0, 0, 0);  // rows >= N must be ZERO (0 * garbage could be NaN)
-      if (vr < p.N) vreg[i] = *reinterpret_cast<const uint4*>(vg + ((int64_t)vr * p.vsn + (c % VCH) * 8) * 2);
+      const int c = tid + i * T, vr = c / VCH, cc = c % VCH;
+      v_wr[i] = vr * (2 * D) + ((((cc >> 2) ^ v_win_swz<D>(vr))) << 6) + ((cc & 3) << 4);
+    }
+  }
+  // K(j) -> K buffer `buf`
+  auto dma_k = [&](const int j, const int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i)
+      if (KC * T == 64 * KCH || wave * 64 + i * T < 64 * KCH)
+        lds_dma16(k_rsrc, k_lds + buf * KBYTES + (wave * 64 + i * T) * 16, k_voff[i], j * k_tile_stride);
+  };
+  // V(j) -> V buffer `buf` (DMA), or -> registers (bf16 path; written to LDS by store_v)
+  auto load_v = [&](const int j, const int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+      if constexpr (V_DMA)
+        lds_dma16(v_rsrc, v_lds + buf * VBYTES + (wave * 64 + i * T) * 16, v_voff[i], j * v_tile_stride);
+      else
+        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff[i], j * v_tile_stride, 0);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_v = [&](const int buf) __attribute__((always_inline)) {
+    if constexpr (!V_DMA) {
 #pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      const int c = tid + i * T;
-      if (KC * T == 64 * KCH || c < 64 * KCH) {
-        const int kr = c / KCH, cc = c % KCH;
-        *reinterpret_cast<uint4*>(k_lds + buf * KBYTES + kr * D + ((cc ^ k_swz<D>(kr)) << 4)) = kreg[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < VC; ++i) {
-      const int c = tid + i * T;
-      const int vr = c / VCH, cc = c % VCH;
-      uint4 u = vreg[i];
-      if constexpr (V_BF16) {  // core.py:633 `v.to(torch.float16)`, fused into the staging pass
+      for (int i = 0; i < VC; ++i) {
+        u32x4 u = vreg[i];
         float f[8];
-        unpack8<true>(u, f);
-        uint32_t w[4];
+        unpack8<true>(make_uint4(u[0], u[1], u[2], u[3]), f);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          w[e] = (uint32_t)f32_to_elem_bits<false>(f[2 * e]) | ((uint32_t)f32_to_elem_bits<false>(f[2 * e + 1]) << 16);
-        u = make_uint4(w[0], w[1], w[2], w[3]);
+          u[e] = (uint32_t)f32_to_elem_bits<false>(f[2 * e]) | ((uint32_t)f32_to_elem_bits<false>(f[2 * e + 1]) << 16);
+        *reinterpret_cast<u32x4*>(v_lds + buf * VBYTES + v_wr[i]) = u;
       }
-      *reinterpret_cast<uint4*>(v_lds + buf * VBYTES + vr * (2 * D) + ((((cc >> 2) ^ v_win_swz<D>(vr))) << 6) +
-                                ((cc & 3) << 4)) = u;
     }
   };
 
@@ -186,152 +217,217 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc_o[dt][e] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f;
+  // Row sums ride on the matrix pipe: l^T += ones(32x16) . P^T, every row of the 32x32 result is the same row sum
+  // of the ROUNDED fp16 P (as the reference: attn_utils.cuh:543-547 / mma.cuh:685-700 "rowsum via mma with ones").
+  v16f acc_l;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc_l[e] = 0.f;
+  v8h ones8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
   // The int32 accumulator of S^T starts at the BIT PATTERN of 1.5*2^23: for |S| < 2^22 (|S| <= 128*127^2) the
   // accumulated integer, reinterpreted as fp32, IS the float 12582912 + S exactly, so the logit needs no
   // v_cvt_f32_i32: t - m = fma(as_float(acc), scale, -(12582912*scale + m)).
   constexpr int kBiasI = 0x4B400000;
   constexpr float kBiasF = 12582912.0f;
+  constexpr int kMaskedI = kBiasI - (1 << 22);  // below every real score
   v16i bias;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = kBiasI;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  // One KV tile for this wave.  MASKED: tiles crossing the causal diagonal or the end of the sequence.
-  auto tile = [&](const int j, const int buf, auto masked_tag) __attribute__((always_inline)) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-    const int n0 = j << 6;
-    // ---- S^T = K . Q^T  (2 tiles of 32 keys x 32 query rows)
-    v16i s_acc[2];
+  // S^T = K . Q^T for one tile (2 x 32 keys x 32 query rows) out of LDS buffer `kbuf`
+  auto qk = [&](const int kbuf, v16i (&s)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const v4i a = *reinterpret_cast<const v4i*>(k_lds + buf * KBYTES + mt * 32 * D + k_rd[ks]);
-        s_acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : s_acc[mt], 0, 0, 0);
+#ifdef SAGE_ABL_NOQK
+        s[mt] = bias; s[mt][0] += kbuf + ks;
+#else
+        const v4i a = *reinterpret_cast<const v4i*>(k_lds + kbuf * KBYTES + mt * 32 * D + k_rd[ks]);
+        s[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : s[mt], 0, 0, 0);
+#endif
       }
-    }
-    // ---- dequantisation scales of this tile
-    float sc0, sc1;
-    if constexpr (KTHREAD) {  // …sm80.cu:131: 4 scales per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
-      sc0 = qsc * ksp[j * 4 + 2 * hh];
-      sc1 = qsc * ksp[j * 4 + 2 * hh + 1];
+  };
+  // dequantisation scales of tile j: …sm80.cu:131, 4 per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
+  auto tile_scales = [&](const int j, float& sc0, float& sc1) __attribute__((always_inline)) {
+    if constexpr (KTHREAD) {
+      typedef unsigned int u32x2 __attribute__((__vector_size__(8)));
+      const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(ks_rsrc, 8 * hh, j * 16, 0);
+      sc0 = qsc * __uint_as_float(kk[0]);
+      sc1 = qsc * __uint_as_float(kk[1]);
     } else {
       sc0 = sc1 = qsc * ksp[j];
     }
-    if constexpr (MASKED) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          const bool bad = (kv >= p.N) || (CAUSAL && kv > row);
-          s_acc[mt][e] = bad ? (kBiasI - (1 << 22)) : s_acc[mt][e];  // below every real score: loses the max
-        }
-    }
-    // ---- row max on the raw integers (scales are positive): v_max3_i32, then one convert per scale group
-    int mxa = s_acc[0][0], mxb = s_acc[0][2];
+  };
+  auto mask_scores = [&](const int j, v16i (&s)[2]) __attribute__((always_inline)) {
+    const int n0 = j << 6;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        if (e & 2) mxb = max(mxb, s_acc[mt][e]); else mxa = max(mxa, s_acc[mt][e]);
+        const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        s[mt][e] = ((kv >= p.N) || (CAUSAL && kv > row)) ? kMaskedI : s[mt][e];
+      }
+  };
+  // row max of the logits of one tile, from the raw integers (scales are positive): v_max3_i32 + 1 cvt/group
+  auto row_max = [&](const v16i (&s)[2], const float sc0, const float sc1) __attribute__((always_inline)) -> float {
+    int mxa = s[0][0], mxb = s[0][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (e & 2) mxb = max(mxb, s[mt][e]); else mxa = max(mxa, s[mt][e]);
       }
     float mx;
     if constexpr (KTHREAD) mx = fmaxf((float)(mxa - kBiasI) * sc0, (float)(mxb - kBiasI) * sc1);
     else mx = (float)(max(mxa, mxb) - kBiasI) * sc0;
-    mx = swap_max(mx);
-    // ---- lazy rescale (attn_utils.cuh:354-458 rescales every tile; here only when some row's max grew by
-    //      more than kLazyThr, so p <= 2^kLazyThr, harmless in fp16/fp32; m_run stays exact for the LSE)
-    constexpr float kLazyThr = 6.0f;
+    return swap_max(mx);
+  };
+  // lazy rescale (attn_utils.cuh:354-458 rescales every tile; here only when some row's max grew by more than
+  // kLazyThr, so p <= 2^kLazyThr -- harmless in fp16/fp32; m_run stays exact for the LSE)
+  constexpr float kLazyThr = 6.0f;
+  auto maybe_rescale = [&](const float mx) __attribute__((always_inline)) {
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m_run + kLazyThr) != 0, 0)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
-      l_run *= alpha;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc_l[e] *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[dt][e] *= alpha;
     }
-    // ---- p = exp2(t - m), fp16 P^T fragments, fp32 row sum
+  };
+  // p = exp2(t - m) in quarters of 16 keys, each followed by its PV MFMAs: O^T += V^T . P^T
+  auto softmax_pv = [&](const int j, const int vbuf, const v16i (&s)[2], const float sc0, const float sc1,
+                        auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int n0 = j << 6;
     const float c0 = __builtin_fmaf(-kBiasF, sc0, -m_run), c1 = __builtin_fmaf(-kBiasF, sc1, -m_run);
-    float psum0 = 0.f, psum1 = 0.f;
-    v8h pf[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int sq = 0; sq < 2; ++sq) {
+        v8h pf;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const bool g1 = (e & 2) != 0;
-          float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s_acc[mt][8 * s + e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
-          float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s_acc[mt][8 * s + e + 1]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+#ifdef SAGE_ABL_NOEXP
+          float p0 = __builtin_fmaf(__int_as_float(s[mt][8 * sq + e]), g1 ? sc1 : sc0, g1 ? c1 : c0);
+          float p1 = __builtin_fmaf(__int_as_float(s[mt][8 * sq + e + 1]), g1 ? sc1 : sc0, g1 ? c1 : c0);
+#else
+          float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][8 * sq + e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+          float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][8 * sq + e + 1]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+#endif
           if constexpr (MASKED) {
-            const int kv = n0 + 32 * mt + ((8 * s + e) & 3) + 8 * ((8 * s + e) >> 2) + 4 * hh;
+            const int kv = n0 + 32 * mt + ((8 * sq + e) & 3) + 8 * ((8 * sq + e) >> 2) + 4 * hh;
             p0 = ((kv >= p.N) || (CAUSAL && kv > row)) ? 0.f : p0;
             p1 = ((kv + 1 >= p.N) || (CAUSAL && kv + 1 > row)) ? 0.f : p1;
           }
-          psum0 += p0;
-          psum1 += p1;
           v2f pp = {p0, p1};
           const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
-          pf[mt][s][e] = ph[0];
-          pf[mt][s][e + 1] = ph[1];
+          pf[e] = ph[0];
+          pf[e + 1] = ph[1];
         }
-    l_run += psum0 + psum1;
-    // ---- O^T += V^T . P^T
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
+        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf, acc_l, 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const char* base = v_lds + buf * VBYTES + (32 * mt + 16 * s) * (2 * D) + v_rd[dt];
-          const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4s_vs*)(base));
+          const char* base = v_lds + vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D) + v_rd[dt];
+          const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
           const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
           v8h a;
           a.s0123 = __builtin_bit_cast(v4h, lo);
           a.s4567 = __builtin_bit_cast(v4h, hi);
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[mt][s], acc_o[dt], 0, 0, 0);
+#ifdef SAGE_ABL_NOPV
+          asm volatile("" ::"v"(a), "v"(pf));
+#else
+          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, acc_o[dt], 0, 0, 0);
+#endif
         }
+      }
   };
 
-  // Three straight-line loops (the O accumulator must not flow through merge points in the hot loop):
-  //   [0, n_plain)            tiles fully inside the causal triangle and the sequence: no mask code
-  //   [n_plain, wave_tiles)   tiles crossing the diagonal / the end of the sequence
-  //   [wave_tiles, ntiles)    causal only: this wave is done but still stages tiles for its workgroup
-  // Every wave executes exactly ntiles barriers.
+  // ---- software pipeline.  LDS: K(j) in K buffer j&1, V(j) in V buffer j&1.  During iteration j the wave
+  //      computes S(j+1) = K(j+1).Q^T (MFMA) while it exponentiates S(j) (VALU) and accumulates P(j).V(j);
+  //      K(j+2) and V(j+1) travel global -> registers during the iteration and registers -> LDS at its end.
+  //   [0, n_fast)           tiles j and j+1 both unmasked: branch-free body
+  //   [n_fast, wave_tiles)  generic body (masks, last tile)
+  //   [wave_tiles, ntiles)  causal only: this wave is done but still stages tiles for its workgroup
+  // Every wave executes the same number of barriers.
   int n_plain = wave_tiles;
   if (p.N & 63) n_plain = min(n_plain, p.N >> 6);
   if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
-  int j = 0;
-  for (; j < n_plain; ++j) {
-    const int buf = j & 1;
-    if (j + 1 < ntiles) load_tile(j + 1);
-    tile(j, buf, std::false_type{});
-    if (j + 1 < ntiles) store_tile(buf ^ 1);
+  const int n_fast = max(0, min(n_plain - 1, wave_tiles - 1));
+  auto needs_mask = [&](const int j) { return ((j << 6) + 64 > p.N) || (CAUSAL && ((j << 6) + 63 > q0)); };
+
+  dma_k(0, 0);
+  load_v(0, 0);
+  store_v(0);
+  if (ntiles > 1) dma_k(1, 1);
+  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the tiles
+
+  v16i s_cur[2], s_nxt[2];
+  float sc0, sc1, mx_cur;
+  qk(0, s_cur);
+  tile_scales(0, sc0, sc1);
+  if (needs_mask(0)) mask_scores(0, s_cur);
+  mx_cur = row_max(s_cur, sc0, sc1);
+
+  // fast loop, unrolled by two so that S(j) / S(j+1) swap roles without register copies
+  auto fast_iter = [&](auto par_tag, const int j, v16i (&sa)[2], v16i (&sb)[2], float& a0, float& a1, float& b0,
+                       float& b1) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;  // j & 1, static so every LDS offset is an immediate
+    maybe_rescale(mx_cur);
+#ifndef SAGE_ABL_NOSTAGE
+    if (j + 2 < ntiles) dma_k(j + 2, PAR);
+    load_v(j + 1, PAR ^ 1);
+#endif
+    tile_scales(j + 1, b0, b1);
+    qk(PAR ^ 1, sb);
+    softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
+    mx_cur = row_max(sb, b0, b1);
+#ifndef SAGE_ABL_NOSTAGE
+    store_v(PAR ^ 1);
+#endif
+#ifndef SAGE_ABL_NOBAR
     __syncthreads();
+#endif
+  };
+  float nsc0 = 0.f, nsc1 = 0.f;
+  int j = 0;
+  for (; j + 1 < n_fast; j += 2) {
+    fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+    fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
   for (; j < wave_tiles; ++j) {
-    const int buf = j & 1;
-    if (j + 1 < ntiles) load_tile(j + 1);
-    tile(j, buf, std::true_type{});
-    if (j + 1 < ntiles) store_tile(buf ^ 1);
+    maybe_rescale(mx_cur);
+    if (j + 2 < ntiles) dma_k(j + 2, j & 1);
+    if (j + 1 < ntiles) load_v(j + 1, (j + 1) & 1);
+    const bool has_next = j + 1 < wave_tiles;
+    if (has_next) {
+      tile_scales(j + 1, nsc0, nsc1);
+      qk((j + 1) & 1, s_nxt);
+      if (needs_mask(j + 1)) mask_scores(j + 1, s_nxt);
+    }
+    softmax_pv(j, j & 1, s_cur, sc0, sc1, std::true_type{});
+    if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
+    if (j + 1 < ntiles) store_v((j + 1) & 1);
     __syncthreads();
+    s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
+    sc0 = nsc0; sc1 = nsc1;
   }
   for (; j < ntiles; ++j) {
-    if (j + 1 < ntiles) { load_tile(j + 1); store_tile((j & 1) ^ 1); }
+    if (j + 2 < ntiles) dma_k(j + 2, j & 1);
+    if (j + 1 < ntiles) { load_v(j + 1, (j + 1) & 1); store_v((j + 1) & 1); }
     __syncthreads();
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
-  const float l_tot = swap_sum(l_run);
+  const float l_tot = acc_l[0];  // the MFMA's k dimension spans both lane halves: already the full row sum
   const float inv = 1.0f / l_tot;
   if (row < p.M) {
     uint16_t* op = p.o + b * p.osb + h * p.osh + (int64_t)row * p.osn;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""In-process A/B of several builds of libsageattn_hip.so (cdna guide rule 24: interleaved rounds in ONE process).
+usage: ab_bench.py [--wl c3] [--rounds 7] [--iters 5] lib_a.so lib_b.so ...   (NWAVES via name suffix @4/@8)"""
+import argparse, ctypes, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sageattention_amd as sa
+from sageattention_amd import _lib as L, core
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--wl", default="c3")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("libs", nargs="+")
+a = ap.parse_args()
+B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
+                      "c2c": (4, 32, 2048, 64, True), "c16k": (2, 32, 16384, 128, False),
+                      "d64_8k": (4, 32, 8192, 64, False)}[a.wl]
+torch.manual_seed(0)
+q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+km = sa.quant.k_mean(k)
+q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
+o = torch.empty_like(q)
+ref = None
+variants = []
+for spec in a.libs:
+    path, _, nw = spec.partition("@")
+    l = ctypes.CDLL(os.path.abspath(path))
+    for name, (res, args) in L.SIGNATURES.items():
+        if hasattr(l, name):
+            fn = getattr(l, name); fn.restype, fn.argtypes = res, args
+    variants.append((spec, l, int(nw) if nw else 0))
+st = torch.cuda.current_stream().cuda_stream
+def run(l, nw):
+    l.sage_set_tuning(0, nw)
+    r = l.sage_attn_qk_int8_pv_f16(L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(v, "HND"), 0, L.desc(o, "HND"), 0,
+                                   qs.data_ptr(), ks.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
+                                   D ** -0.5, 0, st)
+    assert r == 0, r
+times = {s: [] for s, _, _ in variants}
+for s, l, nw in variants:  # warmup + consistency
+    run(l, nw); torch.cuda.synchronize()
+    cur = o.float().clone()
+    if ref is None: ref = cur
+    print(s, "max|o - first variant| =", (cur - ref).abs().max().item())
+for r in range(a.rounds):
+    for s, l, nw in variants:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters): run(l, nw)
+        e1.record(); torch.cuda.synchronize()
+        times[s].append(e0.elapsed_time(e1) / a.iters)
+fl = 4.0 * B * H * N * N * D / (2 if causal else 1)
+for s, t in times.items():
+    print(f"{s:50s} median {statistics.median(t):.4f} ms  min {min(t):.4f} ms  -> {fl/statistics.median(t)/1e9:.1f} TFLOPS (median)")
