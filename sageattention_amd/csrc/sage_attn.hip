@@ -45,11 +45,57 @@ __device__ __forceinline__ float swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// 16 bytes per lane, global/buffer -> LDS without passing through VGPRs (buffer_load_dwordx4 ... lds).
-// `lds` must be wave-uniform; lane l lands at lds + 16*l.  Body hidden from the host pass (address-space cast).
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voffset, int soffset) {
+// 16 bytes per lane, buffer -> LDS without passing through VGPRs (buffer_load_dwordx4 ... offen lds).
+// Issued through inline asm ON PURPOSE: hipcc would otherwise treat the copy as a store that may alias every later
+// LDS read and drain it with s_waitcnt vmcnt(0) a few instructions after issue.  Here nothing waits for it until
+// dma_wait_all() in front of the workgroup barrier that publishes the tile, a whole iteration later.
+// `lds_off` = byte offset of the wave's 1 KiB destination inside the workgroup's LDS (wave-uniform; lane l lands at
+// +16*l), `rsrc` = buffer descriptor (4 uniform dwords), `voffset` per lane, `soffset` uniform.
+__device__ __forceinline__ void lds_dma16(v4i rsrc, unsigned lds_off, int voffset, int soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(rsrc), "s"(lds_off), "s"(soffset)
+      : "memory");
+#endif
+}
+__device__ __forceinline__ void dma_wait_all() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// raw buffer descriptor as 4 provably wave-uniform dwords (gfx950: word3 = 0x00020000)
+__device__ __forceinline__ v4i make_rsrc(const void* base, unsigned num_bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  v4i r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)num_bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
+// Loads through the scalar cache (s_load, lgkmcnt) for wave-uniform addresses of read-only data: the constant
+// address space cast is what lets hipcc pick SMEM; hidden from the host pass.
+__device__ __forceinline__ float4 uniform_load4(const float* ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const v4f v = *(const __attribute__((address_space(4))) v4f*)(ptr);
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
+__device__ __forceinline__ float uniform_load1(const float* ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(4))) float*)(ptr);
+#else
+  return 0.f;
 #endif
 }
 
@@ -120,8 +166,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
     qsc = p.q_scale[((int64_t)b * p.Hq + h) * p.gq + qi] * p.logit_mult;
   }
   const float* ksp = p.k_scale + ((int64_t)b * p.Hk + hk) * p.gk;
-  const __amdgpu_buffer_rsrc_t ks_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ksp), 0, p.gk * 4, 0x00020000);
 
   // ---- tile range
   const int kv_end = CAUSAL ? min(p.N, (qb + 1) * QB) : p.N;
@@ -134,10 +178,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
   const int8_t* kg = p.k + b * p.ksb + hk * p.ksh;
   const uint8_t* vg = p.v + (b * p.vsb + hk * p.vsh) * 2;
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int8_t*>(kg), 0, (int)((int64_t)(p.N - 1) * p.ksn + D), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(vg), 0, (int)(((int64_t)(p.N - 1) * p.vsn + D) * 2), 0x00020000);
+  const unsigned k_bytes = (unsigned)((int64_t)(p.N - 1) * p.ksn + D), v_bytes = (unsigned)(((int64_t)(p.N - 1) * p.vsn + D) * 2);
+  const v4i k_rsrc = make_rsrc(kg, k_bytes), v_rsrc_dma = make_rsrc(vg, v_bytes);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
   const int k_tile_stride = 64 * (int)p.ksn, v_tile_stride = 128 * (int)p.vsn;  // bytes per 64 rows
   // LDS-DMA (buffer_load ... lds): a wave instruction writes 64 x 16 B = 1 KiB of LDS LINEARLY (wave-uniform
   // base + 16*lane), so the bank swizzle of the tile image is applied to the per-lane SOURCE offset instead:
@@ -172,14 +215,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
 #pragma unroll
     for (int i = 0; i < KC; ++i)
       if (KC * T == 64 * KCH || wave * 64 + i * T < 64 * KCH)
-        lds_dma16(k_rsrc, k_lds + buf * KBYTES + (wave * 64 + i * T) * 16, k_voff[i], j * k_tile_stride);
+        lds_dma16(k_rsrc, (unsigned)(buf * KBYTES + (wave * 64 + i * T) * 16), k_voff[i], j * k_tile_stride);
   };
   // V(j) -> V buffer `buf` (DMA), or -> registers (bf16 path; written to LDS by store_v)
   auto load_v = [&](const int j, const int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
       if constexpr (V_DMA)
-        lds_dma16(v_rsrc, v_lds + buf * VBYTES + (wave * 64 + i * T) * 16, v_voff[i], j * v_tile_stride);
+        lds_dma16(v_rsrc_dma, (unsigned)(2 * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
       else
         vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff[i], j * v_tile_stride, 0);
     }
@@ -253,12 +296,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   // dequantisation scales of tile j: …sm80.cu:131, 4 per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
   auto tile_scales = [&](const int j, float& sc0, float& sc1) __attribute__((always_inline)) {
     if constexpr (KTHREAD) {
-      typedef unsigned int u32x2 __attribute__((__vector_size__(8)));
-      const u32x2 kk = __builtin_amdgcn_raw_buffer_load_b64(ks_rsrc, 8 * hh, j * 16, 0);
-      sc0 = qsc * __uint_as_float(kk[0]);
-      sc1 = qsc * __uint_as_float(kk[1]);
+      // wave-uniform address: the 4 scales of the tile come through the scalar cache (s_load_dwordx4, lgkmcnt),
+      // not through vmcnt where they would queue behind the tile DMA
+      const float4 kk = uniform_load4(ksp + j * 4);
+      sc0 = qsc * (hh ? kk.z : kk.x);
+      sc1 = qsc * (hh ? kk.w : kk.y);
     } else {
-      sc0 = sc1 = qsc * ksp[j];
+      sc0 = sc1 = qsc * uniform_load1(ksp + j);
     }
   };
   auto mask_scores = [&](const int j, v16i (&s)[2]) __attribute__((always_inline)) {
@@ -368,7 +412,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   load_v(0, 0);
   store_v(0);
   if (ntiles > 1) dma_k(1, 1);
-  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the tiles
+  dma_wait_all();
+  __syncthreads();
 
   v16i s_cur[2], s_nxt[2];
   float sc0, sc1, mx_cur;
@@ -392,6 +437,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
     mx_cur = row_max(sb, b0, b1);
 #ifndef SAGE_ABL_NOSTAGE
     store_v(PAR ^ 1);
+    dma_wait_all();
 #endif
 #ifndef SAGE_ABL_NOBAR
     __syncthreads();
@@ -416,6 +462,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
     softmax_pv(j, j & 1, s_cur, sc0, sc1, std::true_type{});
     if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
     if (j + 1 < ntiles) store_v((j + 1) & 1);
+    dma_wait_all();
     __syncthreads();
     s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
     sc0 = nsc0; sc1 = nsc1;
@@ -423,6 +470,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   for (; j < ntiles; ++j) {
     if (j + 2 < ntiles) dma_k(j + 2, j & 1);
     if (j + 1 < ntiles) { load_v(j + 1, (j + 1) & 1); store_v((j + 1) & 1); }
+    dma_wait_all();
     __syncthreads();
   }
 
@@ -524,7 +572,8 @@ extern "C" int sage_attn_qk_int8_pv_f16(const sage_tensor* q8, const sage_tensor
   p.qgran = qk_gran; p.blkq = blkq; p.warpq = warpq;
   p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD;
-  int nw = g_nwaves_override ? g_nwaves_override : 8;
+  // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
+  int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
   hipStream_t st = (hipStream_t)stream;
   if (nw == 8) {
     p.nqb = (M + 255) / 256;

@@ -15,7 +15,8 @@ ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
                       "c2c": (4, 32, 2048, 64, True), "c16k": (2, 32, 16384, 128, False),
-                      "d64_8k": (4, 32, 8192, 64, False)}[a.wl]
+                      "d64_8k": (4, 32, 8192, 64, False), "c3s": (1, 32, 8192, 128, False), "c3xs": (1, 8, 8192, 128, False),
+                      "c3l": (8, 32, 8192, 128, False)}[a.wl]
 torch.manual_seed(0)
 q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
 k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
