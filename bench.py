@@ -20,7 +20,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-P_MIX_TFLOPS = 3333.0  # 1/(0.5/5000 + 0.5/2500): int8 QK^T at 2x the fp16 PV MFMA rate
+# dense MFMA peaks (MI355X_MICROARCH.md): int8 5.0 POPS, fp16 2.5 PF, MX-scaled fp8 5.0 PF.  Half the flops are the
+# int8 QK^T, half the PV product: P_mix = 1/(0.5/P_qk + 0.5/P_pv)  
+P_MIX_TFLOPS = {"fp16": 3333.0, "fp8": 5000.0}
 
 WORKLOADS = {
     # name: (B, H, N, D, causal, variant)
@@ -150,7 +152,7 @@ def main():
     value = total_flops / (ms_per_step * 1e-3) / 1e12
 
     out = {
-        "metric": "attention fwd TFLOPS at head_dim=128 seqlen=8K (INT8 QK^T + FP16 PV, quantizers included)",
+        "metric": f"attention fwd TFLOPS at head_dim={D} seqlen={N} (INT8 QK^T + {variant.upper()} PV, quantizers included)",
         "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
@@ -177,9 +179,10 @@ def main():
                     _qattn._attn_f8(q8, k8, v8, o, qs, ks, vsc, None, 1, int(causal), code, D ** -0.5, 0)
             k_ms = time_events(kern, args.steps, args.warmup)
             k_tflops = total_flops / (k_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": P_MIX_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(k_tflops / P_MIX_TFLOPS, 4), "traffic": None,
-                               "kernel": "attn_i8_f16_kernel" if variant == "fp16" else "attn_i8_f8_kernel",
+            peak = P_MIX_TFLOPS[variant]
+            out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(k_tflops / peak, 4), "traffic": None,
+                               "kernel": f"attn_i8_kernel<D={D}, pv={variant}>",
                                "kernel_ms": round(k_ms, 4), "flops_per_launch": total_flops}
             pre_ms = time_events(lambda: sacore._quant_qk(q, k, sa.quant.k_mean(k), "HND", args.gran, D ** -0.5, 32,
                                                           False, H, H), args.steps, args.warmup)

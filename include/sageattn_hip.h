@@ -122,7 +122,12 @@ int sage_sub_mean_f16(const sage_tensor* v, int dtype, int B, int H, int N, int 
  * v_scale[b,h,d] = amax_d/scale_max (fp32 [B,H,D]); v_mean (optional, fp32 [B,H,D]): when non
  * null the channel mean (sum/ceil16(N), fused.cu:335,381) is subtracted first.
  * The reference's 16-row permutation (quant.py:234) is an NVIDIA mma-fragment artefact and is
- * not applied (the fork's HIP port disables it too, fused.hip:362-367).
+ * not applied (the fork's HIP port disables it too, fused.hip:362-367).  Its gfx950 counterpart IS:
+ * inside every 64-token block position pos holds token
+ *   32*((pos&31)>>4) + (pos&3) + 8*((pos&15)>>2) + 4*(pos>>5)
+ * ("MFMA order": the k order in which v_mfma_scale_f32_32x32x64_f8f6f4 receives P^T out of the S^T
+ * accumulators), so v_fp8 is an opaque operand of sage_attn_qk_int8_pv_f8.  Columns of tokens >= N
+ * are zero.
  * workspace: sage_quant_v_fp8_workspace_bytes(B,H,N,D) bytes. */
 size_t sage_quant_v_fp8_workspace_bytes(int B, int H, int N, int D);
 int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D,

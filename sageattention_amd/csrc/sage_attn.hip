@@ -34,6 +34,7 @@ struct AttnParams {
   int gq, gk;   // scales per (b,h)
   int qgran, blkq, warpq;
   float logit_mult;
+  int out_bf16;
 };
 
 __device__ __forceinline__ float swap_max(float x) {
@@ -110,19 +111,24 @@ __device__ __forceinline__ int v_win_swz(int row) {
   if constexpr (D == 128) return row & 3; else return (row >> 1) & 1;
 }
 
-template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool OUT_BF16, bool V_BF16>
-__global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnParams p) {
+// PV_FP8 = false: V fp16 [N][D] row major (bf16 converted on the fly), PV on v_mfma_f32_32x32x16_f16.
+// PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
+//                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
+template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8>
+__global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParams p) {
+  static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
   constexpr int T = NWAVES * 64;
   constexpr int QB = NWAVES * 32;
   constexpr int KS = D / 32;          // k-steps of the int8 QK^T MFMA
   constexpr int DT = D / 32;          // 32-wide d tiles of O^T
   constexpr int KBYTES = 64 * D;      // one K tile (int8)
-  constexpr int VBYTES = 64 * D * 2;  // one V tile (fp16)
+  constexpr int VBYTES = PV_FP8 ? 64 * D : 64 * D * 2;  // one V tile: fp16 [64][D] or e4m3 [D][64]
   constexpr int KCH = D / 16;         // 16-B chunks per K row
-  constexpr int VCH = D / 8;          // 16-B chunks per V row
-  constexpr int KC = (64 * KCH + T - 1) / T;  // chunks per thread
-  constexpr int VC = (64 * VCH) / T;
-  static_assert((64 * VCH) % T == 0, "V tile must divide over the workgroup");
+  constexpr int VCH = PV_FP8 ? 4 : D / 8;       // 16-B chunks per V tile row (fp8: a V^T row holds 64 tokens)
+  constexpr int VROWS = PV_FP8 ? D : 64;        // rows of the V tile image
+  constexpr int KC = (64 * KCH + T - 1) / T;    // chunks per thread
+  constexpr int VC = (VROWS * VCH + T - 1) / T;
+  static_assert(PV_FP8 || (64 * VCH) % T == 0, "V tile must divide over the workgroup");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const k_lds = smem;
@@ -177,11 +183,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   //      tile costs no address VALU; rows >= N fall outside num_records and read as ZERO (V rows beyond the
   //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
   const int8_t* kg = p.k + b * p.ksb + hk * p.ksh;
-  const uint8_t* vg = p.v + (b * p.vsb + hk * p.vsh) * 2;
-  const unsigned k_bytes = (unsigned)((int64_t)(p.N - 1) * p.ksn + D), v_bytes = (unsigned)(((int64_t)(p.N - 1) * p.vsn + D) * 2);
+  const uint8_t* vg = p.v + (b * p.vsb + hk * p.vsh) * (PV_FP8 ? 1 : 2);
+  const unsigned k_bytes = (unsigned)((int64_t)(p.N - 1) * p.ksn + D);
+  const unsigned v_bytes = PV_FP8 ? (unsigned)((int64_t)(D - 1) * p.vsn + ((p.N + 63) & ~63))
+                                  : (unsigned)(((int64_t)(p.N - 1) * p.vsn + D) * 2);
   const v4i k_rsrc = make_rsrc(kg, k_bytes), v_rsrc_dma = make_rsrc(vg, v_bytes);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
-  const int k_tile_stride = 64 * (int)p.ksn, v_tile_stride = 128 * (int)p.vsn;  // bytes per 64 rows
+  const int k_tile_stride = 64 * (int)p.ksn;                          // bytes per 64 keys
+  const int v_tile_stride = PV_FP8 ? 64 : 128 * (int)p.vsn;
   // LDS-DMA (buffer_load ... lds): a wave instruction writes 64 x 16 B = 1 KiB of LDS LINEARLY (wave-uniform
   // base + 16*lane), so the bank swizzle of the tile image is applied to the per-lane SOURCE offset instead:
   // LDS chunk position c of a tile holds global chunk (row(c), pos(c) ^ swizzle(row)).  No VGPR staging, no
@@ -197,8 +206,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
     const int c = tid + i * T, vr = c / VCH, pos = c % VCH;
-    const int cc = V_DMA ? ((((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3)) : pos;
-    v_voff[i] = (vr * (int)p.vsn + cc * 8) * 2;
+    if constexpr (PV_FP8) {
+      v_voff[i] = vr * (int)p.vsn + ((pos ^ ((vr >> 2) & 3)) << 4);  // V^T row vr (= channel), 16-B chunk swizzle
+    } else {
+      const int cc = V_DMA ? ((((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3)) : pos;
+      v_voff[i] = (vr * (int)p.vsn + cc * 8) * 2;
+    }
   }
   typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
   u32x4 vreg[V_DMA ? 1 : VC];
@@ -221,6 +234,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   auto load_v = [&](const int j, const int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
+      if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
       if constexpr (V_DMA)
         lds_dma16(v_rsrc_dma, (unsigned)(2 * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
       else
@@ -246,7 +260,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   int k_rd[KS];  // K A-fragment: row r (+32*mt via immediate), chunk 2*ks+hh
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * D + (((2 * ks + hh) ^ k_swz<D>(r)) << 4);
-  int v_rd[DT];  // V^T fragment via tr-read: row 4*hh + q4 (+32*mt+16*s(+8) immediate), window dt
+  int v_rd8[2];  // fp8: V^T row r (+32*dt immediate), 16-B chunks 2*hh and 2*hh+1
+#pragma unroll
+  for (int c = 0; c < 2; ++c) v_rd8[c] = r * 64 + (((2 * hh + c) ^ ((r >> 2) & 3)) << 4);
+  int v_rd[DT];  // fp16: V^T fragment via tr-read: row 4*hh + q4 (+32*mt+16*s(+8) immediate), window dt
   {
     const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g = (lane >> 4) & 1;
     const int rv = 4 * hh + q4;
@@ -261,6 +278,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc_o[dt][e] = 0.f;
   float m_run = -1e30f;
+  float l_run = 0.f;  // fp8 path only: fp32 row sum of the UNROUNDED p, as the reference's fp8 kernel
+                      // (ComputeUnit::kCudaCore, sm89_*.cu:148, attn_utils.cuh:549-553)
   // Row sums ride on the matrix pipe: l^T += ones(32x16) . P^T, every row of the 32x32 result is the same row sum
   // of the ROUNDED fp16 P (as the reference: attn_utils.cuh:543-547 / mma.cuh:685-700 "rowsum via mma with ones").
   v16f acc_l;
@@ -331,12 +350,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   };
   // lazy rescale (attn_utils.cuh:354-458 rescales every tile; here only when some row's max grew by more than
   // kLazyThr, so p <= 2^kLazyThr -- harmless in fp16/fp32; m_run stays exact for the LSE)
-  constexpr float kLazyThr = 6.0f;
+  // fp8: p carries the reference's exponent offset (attn_utils.cuh:30,379: m tracked as t - 8.807 so p <= 448 = e4m3
+  // max); the lazy threshold is taken out of that headroom so p <= 2^(kLazyThr + kPOff) = 448 still holds.
+  constexpr float kLazyThr = PV_FP8 ? 3.0f : 6.0f;
+  constexpr float kPOff = PV_FP8 ? 8.807f - 3.0f : 0.f;
   auto maybe_rescale = [&](const float mx) __attribute__((always_inline)) {
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m_run + kLazyThr) != 0, 0)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc_l[e] *= alpha;
 #pragma unroll
@@ -345,54 +368,82 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
         for (int e = 0; e < 16; ++e) acc_o[dt][e] *= alpha;
     }
   };
-  // p = exp2(t - m) in quarters of 16 keys, each followed by its PV MFMAs: O^T += V^T . P^T
+  // p = exp2(t - m) and O^T += V^T . P^T
   auto softmax_pv = [&](const int j, const int vbuf, const v16i (&s)[2], const float sc0, const float sc1,
                         auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     const int n0 = j << 6;
-    const float c0 = __builtin_fmaf(-kBiasF, sc0, -m_run), c1 = __builtin_fmaf(-kBiasF, sc1, -m_run);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int sq = 0; sq < 2; ++sq) {
-        v8h pf;
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const bool g1 = (e & 2) != 0;
+    const float c0 = __builtin_fmaf(-kBiasF, sc0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, sc1, kPOff - m_run);
+    auto prob = [&](const int mt, const int e) __attribute__((always_inline)) -> float {
+      const bool g1 = (e & 2) != 0;
 #ifdef SAGE_ABL_NOEXP
-          float p0 = __builtin_fmaf(__int_as_float(s[mt][8 * sq + e]), g1 ? sc1 : sc0, g1 ? c1 : c0);
-          float p1 = __builtin_fmaf(__int_as_float(s[mt][8 * sq + e + 1]), g1 ? sc1 : sc0, g1 ? c1 : c0);
+      float pv = __builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0);
 #else
-          float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][8 * sq + e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
-          float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][8 * sq + e + 1]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
 #endif
-          if constexpr (MASKED) {
-            const int kv = n0 + 32 * mt + ((8 * sq + e) & 3) + 8 * ((8 * sq + e) >> 2) + 4 * hh;
-            p0 = ((kv >= p.N) || (CAUSAL && kv > row)) ? 0.f : p0;
-            p1 = ((kv + 1 >= p.N) || (CAUSAL && kv + 1 > row)) ? 0.f : p1;
-          }
-          v2f pp = {p0, p1};
-          const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
-          pf[e] = ph[0];
-          pf[e + 1] = ph[1];
-        }
-        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf, acc_l, 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const char* base = v_lds + vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D) + v_rd[dt];
-          const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
-          const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
-          v8h a;
-          a.s0123 = __builtin_bit_cast(v4h, lo);
-          a.s4567 = __builtin_bit_cast(v4h, hi);
-#ifdef SAGE_ABL_NOPV
-          asm volatile("" ::"v"(a), "v"(pf));
-#else
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, acc_o[dt], 0, 0, 0);
-#endif
-        }
+      if constexpr (MASKED) {
+        const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        pv = ((kv >= p.N) || (CAUSAL && kv > row)) ? 0.f : pv;
       }
+      return pv;
+    };
+    if constexpr (!PV_FP8) {
+      // quarters of 16 keys, each followed by its PV MFMAs (and the ones-row MFMA that sums the rounded P)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+          v8h pf;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            v2f pp = {prob(mt, 8 * sq + e), prob(mt, 8 * sq + e + 1)};
+            const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
+            pf[e] = ph[0];
+            pf[e + 1] = ph[1];
+          }
+          acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf, acc_l, 0, 0, 0);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const char* base = v_lds + vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D) + v_rd[dt];
+            const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
+            const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
+            v8h a;
+            a.s0123 = __builtin_bit_cast(v4h, lo);
+            a.s4567 = __builtin_bit_cast(v4h, hi);
+#ifdef SAGE_ABL_NOPV
+            asm volatile("" ::"v"(a), "v"(pf));
+#else
+            acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, acc_o[dt], 0, 0, 0);
+#endif
+          }
+        }
+    } else {
+      // all 64 keys of the tile in one K=64 MFMA per d tile; P^T bytes in accumulator order j = 16*mt + reg
+      v8i pb;
+      float psum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const int mt = w >> 2, e0 = 4 * (w & 3);
+        const float p0 = prob(mt, e0), p1 = prob(mt, e0 + 1), p2 = prob(mt, e0 + 2), p3 = prob(mt, e0 + 3);
+        psum += p0; psum += p1; psum += p2; psum += p3;
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, 0, false);  // OCP e4m3, RNE (e4m3_rn_satfinite)
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, pk, true);
+        pb[w] = pk;
+      }
+      l_run += psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char* base = v_lds + vbuf * VBYTES + dt * 32 * 64;
+        const v4i lo = *reinterpret_cast<const v4i*>(base + v_rd8[0]);
+        const v4i hi = *reinterpret_cast<const v4i*>(base + v_rd8[1]);
+        v8i a;
+        a.s0123 = lo;
+        a.s4567 = hi;
+        // cbsz = blgp = 0: both operands e4m3; E8M0 block scales 127 = 2^0
+        acc_o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pb, acc_o[dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    }
   };
 
   // ---- software pipeline.  LDS: K(j) in K buffer j&1, V(j) in V buffer j&1.  During iteration j the wave
@@ -475,7 +526,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
-  const float l_tot = acc_l[0];  // the MFMA's k dimension spans both lane halves: already the full row sum
+  // fp16: the ones-row MFMA's k dimension spans both lane halves -> already the full row sum
+  const float l_tot = PV_FP8 ? swap_sum(l_run) : acc_l[0];
   const float inv = 1.0f / l_tot;
   if (row < p.M) {
     uint16_t* op = p.o + b * p.osb + h * p.osh + (int64_t)row * p.osn;
@@ -489,37 +541,48 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_f16_kernel(const AttnP
           float x[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = acc_o[dt][4 * g4 + e] * inv;
+          if constexpr (PV_FP8) {  // fuse_v_scale (qk_int_sv_f8_cuda_sm89.cuh:578-626)
+            const float4 vs = *reinterpret_cast<const float4*>(p.v_scale + ((int64_t)b * p.Hk + hk) * D + d0);
+            x[0] *= vs.x; x[1] *= vs.y; x[2] *= vs.z; x[3] *= vs.w;
+          }
           if constexpr (decltype(has_vm)::value) {
             const float4 vmv = *reinterpret_cast<const float4*>(vmp + d0);
             x[0] += vmv.x; x[1] += vmv.y; x[2] += vmv.z; x[3] += vmv.w;
           }
           uint2 w;
-          w.x = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[0]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[1]) << 16);
-          w.y = (uint32_t)f32_to_elem_bits<OUT_BF16>(x[2]) | ((uint32_t)f32_to_elem_bits<OUT_BF16>(x[3]) << 16);
+          if (p.out_bf16) {
+            w.x = (uint32_t)f32_to_elem_bits<true>(x[0]) | ((uint32_t)f32_to_elem_bits<true>(x[1]) << 16);
+            w.y = (uint32_t)f32_to_elem_bits<true>(x[2]) | ((uint32_t)f32_to_elem_bits<true>(x[3]) << 16);
+          } else {
+            w.x = (uint32_t)f32_to_elem_bits<false>(x[0]) | ((uint32_t)f32_to_elem_bits<false>(x[1]) << 16);
+            w.y = (uint32_t)f32_to_elem_bits<false>(x[2]) | ((uint32_t)f32_to_elem_bits<false>(x[3]) << 16);
+          }
           *reinterpret_cast<uint2*>(op + d0) = w;
         }
     };
     if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
-    if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * p.M + row] = m_run + log2f(l_tot);
+    if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * p.M + row] = m_run + log2f(l_tot) - kPOff;
   }
 }
 
-template <int D, int NWAVES>
-static int launch_f16(const AttnParams& p, bool causal, bool kthread, bool out_bf16, bool v_bf16, hipStream_t st) {
-  const size_t smem = 2 * 64 * D + 2 * 64 * D * 2;
+template <int D, int NWAVES, bool PV_FP8>
+static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf16, hipStream_t st) {
+  const size_t smem = 2 * 64 * D + 2 * (PV_FP8 ? 64 * D : 64 * D * 2);
   const dim3 grid(p.nqb * p.Hq * p.B), block(NWAVES * 64);
-#define SAGE_LAUNCH(C, K, O, V)                                                                          \
-  do {                                                                                                   \
-    auto kern = attn_i8_f16_kernel<D, NWAVES, C, K, O, V>;                                              \
+#define SAGE_LAUNCH(C, K, V)                                                                                       \
+  do {                                                                                                             \
+    auto kern = attn_i8_kernel<D, NWAVES, C, K, V, PV_FP8>;                                                        \
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                 \
+    hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                            \
   } while (0)
-#define SAGE_BY_V(C, K, O) do { if (v_bf16) SAGE_LAUNCH(C, K, O, true); else SAGE_LAUNCH(C, K, O, false); } while (0)
-#define SAGE_BY_O(C, K) do { if (out_bf16) SAGE_BY_V(C, K, true); else SAGE_BY_V(C, K, false); } while (0)
-#define SAGE_BY_K(C) do { if (kthread) SAGE_BY_O(C, true); else SAGE_BY_O(C, false); } while (0)
+#define SAGE_BY_V(C, K)                                                                                            \
+  do {                                                                                                             \
+    if constexpr (PV_FP8) SAGE_LAUNCH(C, K, false);                                                                \
+    else { if (v_bf16) SAGE_LAUNCH(C, K, true); else SAGE_LAUNCH(C, K, false); }                                   \
+  } while (0)
+#define SAGE_BY_K(C) do { if (kthread) SAGE_BY_V(C, true); else SAGE_BY_V(C, false); } while (0)
   if (causal) SAGE_BY_K(true); else SAGE_BY_K(false);
 #undef SAGE_BY_K
-#undef SAGE_BY_O
 #undef SAGE_BY_V
 #undef SAGE_LAUNCH
   return launch_status();
@@ -531,6 +594,50 @@ static bool t_ok(const sage_tensor* t, int align_elems) {
 }
 
 int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
+
+// shared argument handling of the two attention entry points
+static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
+                    const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale, const float* v_scale,
+                    const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal, int qk_gran,
+                    int blkq, int warpq, float sm_scale, int logit_mult_is_one, hipStream_t st) {
+  if (!t_ok(q8, 16) || !t_ok(k8, 16) || !t_ok(v, pv_fp8 ? 16 : 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
+  if (pv_fp8 && !v_scale) return SAGE_ERR_INVALID_ARGUMENT;
+  if (B <= 0 || Hq <= 0 || Hk <= 0 || M <= 0 || N <= 0 || Hq % Hk != 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if ((v_dtype != SAGE_F16 && v_dtype != SAGE_BF16) || (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (qk_gran < SAGE_GRAN_PER_BLOCK || qk_gran > SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
+  if (blkq != 64 && blkq != 128) return SAGE_ERR_INVALID_ARGUMENT;
+  if (qk_gran == SAGE_GRAN_PER_BLOCK) warpq = blkq;
+  if ((warpq != 16 && warpq != 32 && warpq != 64 && warpq != 128) || blkq % warpq != 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if ((v_mean && !aligned16(v_mean)) || (v_scale && !aligned16(v_scale))) return SAGE_ERR_INVALID_ARGUMENT;
+  // the K/V slices of one (b, h_kv) are addressed with 32-bit buffer offsets
+  const int64_t lim = (int64_t)1 << 31;
+  const int64_t npad = ((int64_t)N + 63) & ~63ll;
+  if ((int64_t)N * k8->stride_n + D >= lim) return SAGE_ERR_TOO_LARGE;
+  if (pv_fp8 ? ((int64_t)D * v->stride_n + npad >= lim) : (((int64_t)N * v->stride_n + D) * 2 >= lim)) return SAGE_ERR_TOO_LARGE;
+  AttnParams p;
+  p.q = (const int8_t*)q8->data; p.qsb = q8->stride_b; p.qsh = q8->stride_h; p.qsn = q8->stride_n;
+  p.k = (const int8_t*)k8->data; p.ksb = k8->stride_b; p.ksh = k8->stride_h; p.ksn = k8->stride_n;
+  p.v = (const uint8_t*)v->data; p.vsb = v->stride_b; p.vsh = v->stride_h; p.vsn = v->stride_n;
+  p.o = (uint16_t*)o->data; p.osb = o->stride_b; p.osh = o->stride_h; p.osn = o->stride_n;
+  p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean; p.lse = lse;
+  p.B = B; p.Hq = Hq; p.Hk = Hk; p.M = M; p.N = N;
+  const int nblkq = (M + blkq - 1) / blkq;
+  p.gq = qk_gran == SAGE_GRAN_PER_BLOCK ? nblkq : qk_gran == SAGE_GRAN_PER_WARP ? nblkq * (blkq / warpq) : nblkq * (blkq / warpq) * 8;
+  const int nblkk = (N + 63) / 64;
+  p.gk = qk_gran == SAGE_GRAN_PER_THREAD ? nblkk * 4 : nblkk;
+  p.qgran = qk_gran; p.blkq = blkq; p.warpq = warpq;
+  p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
+  p.out_bf16 = o_dtype == SAGE_BF16;
+  const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
+  // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
+  const int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
+  p.nqb = (M + nw * 32 - 1) / (nw * 32);
+#define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
+  if (nw == 8) return D == 64 ? SAGE_GO(64, 8) : SAGE_GO(128, 8);
+  return D == 64 ? SAGE_GO(64, 4) : SAGE_GO(128, 4);
+#undef SAGE_GO
+}
 
 }  // namespace sage
 
@@ -550,37 +657,15 @@ extern "C" int sage_attn_qk_int8_pv_f16(const sage_tensor* q8, const sage_tensor
                                         const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D,
                                         int is_causal, int qk_gran, int blkq, int warpq, float sm_scale,
                                         int logit_mult_is_one, sage_stream_t stream) {
-  if (!t_ok(q8, 16) || !t_ok(k8, 16) || !t_ok(v, 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
-  if (B <= 0 || Hq <= 0 || Hk <= 0 || M <= 0 || N <= 0 || Hq % Hk != 0) return SAGE_ERR_INVALID_ARGUMENT;
-  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
-  if ((v_dtype != SAGE_F16 && v_dtype != SAGE_BF16) || (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16)) return SAGE_ERR_INVALID_ARGUMENT;
-  if (qk_gran < SAGE_GRAN_PER_BLOCK || qk_gran > SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
-  if (blkq != 64 && blkq != 128) return SAGE_ERR_INVALID_ARGUMENT;
-  if (qk_gran == SAGE_GRAN_PER_BLOCK) warpq = blkq;
-  if ((warpq != 16 && warpq != 32 && warpq != 64 && warpq != 128) || blkq % warpq != 0) return SAGE_ERR_INVALID_ARGUMENT;
-  AttnParams p;
-  p.q = (const int8_t*)q8->data; p.qsb = q8->stride_b; p.qsh = q8->stride_h; p.qsn = q8->stride_n;
-  p.k = (const int8_t*)k8->data; p.ksb = k8->stride_b; p.ksh = k8->stride_h; p.ksn = k8->stride_n;
-  p.v = (const uint8_t*)v->data; p.vsb = v->stride_b; p.vsh = v->stride_h; p.vsn = v->stride_n;
-  p.o = (uint16_t*)o->data; p.osb = o->stride_b; p.osh = o->stride_h; p.osn = o->stride_n;
-  p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = nullptr; p.v_mean = v_mean; p.lse = lse;
-  p.B = B; p.Hq = Hq; p.Hk = Hk; p.M = M; p.N = N;
-  const int nblkq = (M + blkq - 1) / blkq;
-  p.gq = qk_gran == SAGE_GRAN_PER_BLOCK ? nblkq : qk_gran == SAGE_GRAN_PER_WARP ? nblkq * (blkq / warpq) : nblkq * (blkq / warpq) * 8;
-  const int nblkk = (N + 63) / 64;
-  p.gk = qk_gran == SAGE_GRAN_PER_THREAD ? nblkk * 4 : nblkk;
-  p.qgran = qk_gran; p.blkq = blkq; p.warpq = warpq;
-  p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
-  const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD;
-  // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
-  int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
-  hipStream_t st = (hipStream_t)stream;
-  if (nw == 8) {
-    p.nqb = (M + 255) / 256;
-    return D == 64 ? launch_f16<64, 8>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st)
-                   : launch_f16<128, 8>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st);
-  }
-  p.nqb = (M + 127) / 128;
-  return D == 64 ? launch_f16<64, 4>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st)
-                 : launch_f16<128, 4>(p, is_causal, kthread, o_dtype == SAGE_BF16, v_dtype == SAGE_BF16, st);
+  return run_attn(q8, k8, v, false, v_dtype, o, o_dtype, q_scale, k_scale, nullptr, v_mean, lse, B, Hq, Hk, M, N, D, is_causal,
+                  qk_gran, blkq, warpq, sm_scale, logit_mult_is_one, (hipStream_t)stream);
+}
+
+extern "C" int sage_attn_qk_int8_pv_f8(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v_fp8,
+                                       const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                       const float* v_scale, const float* v_mean, float* lse, int B, int Hq, int Hk, int M,
+                                       int N, int D, int is_causal, int qk_gran, int blkq, int warpq, float sm_scale,
+                                       int logit_mult_is_one, sage_stream_t stream) {
+  return run_attn(q8, k8, v_fp8, true, SAGE_F16, o, o_dtype, q_scale, k_scale, v_scale, v_mean, lse, B, Hq, Hk, M, N, D,
+                  is_causal, qk_gran, blkq, warpq, sm_scale, logit_mult_is_one, (hipStream_t)stream);
 }

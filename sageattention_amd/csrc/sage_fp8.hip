@@ -1,8 +1,157 @@
-// FP8 (OCP e4m3fn) V quantizer and INT8-QK / FP8-PV attention -- placeholder entry points.
+// K3: FP8 (OCP e4m3fn) per-channel V quantizer for gfx950.
+// Replaces TransposePadPermuteKernel + MeanScaleKernel (csrc/fused/fused.cu:262-427, quant.py:225-322) with
+//   pass 1  per-channel max / min / sum over the sequence (deterministic two-level reduction, no atomics)
+//   pass 2  (x - mean) * scale_max/amax -> e4m3 (RNE, saturating), transposed to [d][token] through LDS
+// HBM-bound; algorithmic traffic 2 B + 2 B read, 1 B written per element (the reference: ~7 B/element through its
+// fp16 transposed temporary).
+//
+// Token order inside each 64-token block ("MFMA order"): the PV product O^T += V^T . P^T runs on
+// v_mfma_scale_f32_32x32x64_f8f6f4 whose B operand is P^T straight out of the S^T accumulators: lane half h, byte j
+// (j = 16*mt + reg) carries key kv(h,j) = 32*(j>>4) + (j&3) + 8*((j&15)>>2) + 4*h.  Storing token kv(pos>>5, pos&31) at
+// position pos makes every A fragment 32 contiguous bytes of a V^T row.  This plays the role of the reference's
+// NVIDIA-fragment permutation (quant.py:234) for the gfx950 fragment; the layout is private to this library.
 #include "sage_common.h"
-extern "C" size_t sage_quant_v_fp8_workspace_bytes(int, int, int, int) { return 0; }
-extern "C" int sage_quant_v_fp8(const sage_tensor*, int, int, int, int, int, const sage_tensor*, float*, float*, float,
-                                void*, sage_stream_t) { return SAGE_ERR_UNSUPPORTED; }
-extern "C" int sage_attn_qk_int8_pv_f8(const sage_tensor*, const sage_tensor*, const sage_tensor*, const sage_tensor*, int,
-                                       const float*, const float*, const float*, const float*, float*, int, int, int, int,
-                                       int, int, int, int, int, int, float, int, sage_stream_t) { return SAGE_ERR_UNSUPPORTED; }
+
+namespace sage {
+
+constexpr int VQ_ROWS = 256;  // tokens per workgroup in pass 1
+
+__host__ __device__ __forceinline__ int mfma_order_token(int pos) {
+  const int h = pos >> 5, j = pos & 31;
+  return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h;
+}
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void v_stats_partial_kernel(const uint16_t* __restrict__ v, int64_t sb, int64_t sh,
+                                                              int64_t sn, int N, float* __restrict__ part, int S) {
+  constexpr int TPR = D / 8, RPP = 256 / TPR;
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  const uint16_t* base = v + b * sb + h * sh + tc * 8;
+  float mx[8], mn[8], sm[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mx[j] = -1000000.0f; mn[j] = 1000000.0f; sm[j] = 0.f; }  // fused.cu:345-347
+#pragma unroll 4
+  for (int i = 0; i < VQ_ROWS / RPP; ++i) {
+    const int row = s * VQ_ROWS + i * RPP + tr;
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tokens in [N, ceil16(N)) count as zeros (fused.cu:335)
+    const int n16 = (N + 15) / 16 * 16;
+    if (row < n16) {
+      if (row < N) unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { mx[j] = fmaxf(mx[j], f[j]); mn[j] = fminf(mn[j], f[j]); sm[j] += f[j]; }
+    }
+  }
+  __shared__ float red[3][RPP][D + 1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][tr][tc * 8 + j] = mx[j]; red[1][tr][tc * 8 + j] = mn[j]; red[2][tr][tc * 8 + j] = sm[j]; }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float a = red[0][0][threadIdx.x], c = red[1][0][threadIdx.x], e = red[2][0][threadIdx.x];
+    for (int r = 1; r < RPP; ++r) {
+      a = fmaxf(a, red[0][r][threadIdx.x]); c = fminf(c, red[1][r][threadIdx.x]); e += red[2][r][threadIdx.x];
+    }
+    float* o = part + ((((int64_t)b * gridDim.y + h) * S + s) * 3) * D + threadIdx.x;
+    o[0] = a; o[D] = c; o[2 * D] = e;
+  }
+}
+
+// per (b,h): finish the reduction; v_scale = amax/scale_max; keep mean and scale_max/amax for pass 2
+__global__ void v_stats_final_kernel(const float* __restrict__ part, int S, int D, int N, float scale_max, int smooth,
+                                     float* __restrict__ v_scale, float* __restrict__ v_mean, float* __restrict__ coef) {
+  const int64_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  float a = -1000000.0f, c = 1000000.0f, e = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* q = part + ((bh * S + s) * 3) * D + d;
+    a = fmaxf(a, q[0]); c = fminf(c, q[D]); e += q[2 * D];
+  }
+  const int n16 = (N + 15) / 16 * 16;
+  const float mean = smooth ? e / (float)n16 : 0.f;  // fused.cu:381: divides by the 16-padded token count
+  const float amax = smooth ? fmaxf(fabsf(a - mean), fabsf(c - mean)) : fmaxf(fabsf(a), fabsf(c));
+  v_scale[bh * D + d] = amax / scale_max;
+  if (smooth) v_mean[bh * D + d] = mean;
+  coef[(bh * 2) * D + d] = mean;
+  coef[(bh * 2 + 1) * D + d] = scale_max / amax;
+}
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void v_quant_transpose_kernel(const uint16_t* __restrict__ v, int64_t sb, int64_t sh,
+                                                                int64_t sn, int N, const float* __restrict__ coef,
+                                                                uint8_t* __restrict__ out, int64_t ob, int64_t oh,
+                                                                int64_t od) {
+  constexpr int TPR = D / 8, RPP = 256 / TPR, NP = 64 / RPP;
+  const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[D][64 + 16];  // [d][pos], padded against bank conflicts
+  float mean[8], rcp[8];
+  {
+    const float* cf = coef + (((int64_t)b * H + h) * 2) * D + tc * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mean[j] = cf[j]; rcp[j] = cf[D + j]; }
+  }
+  // inverse of mfma_order_token on 64 positions: token t sits at position pos(t)
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int t = i * RPP + tr;  // token within the block
+    const int row = blk * 64 + t;
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < N) unpack8<BF16>(*reinterpret_cast<const uint4*>(v + b * sb + h * sh + (int64_t)row * sn + tc * 8), f);
+    // t = 32*mt + (reg&3) + 8*(reg>>2) + 4*hh  ->  pos = 32*hh + 16*mt + reg
+    const int mt = t >> 5, w = t & 31, hh = (w >> 2) & 1, reg = (w & 3) | ((w >> 3) << 2);
+    const int pos = 32 * hh + 16 * mt + reg;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const float x0 = row < N ? (f[j] - mean[j]) * rcp[j] : 0.f;          // pad columns are exact zeros
+      const float x1 = row < N ? (f[j + 1] - mean[j + 1]) * rcp[j + 1] : 0.f;
+      const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);      // OCP e4m3fn, RNE, saturating
+      tile[tc * 8 + j][pos] = (uint8_t)(pk & 0xff);
+      tile[tc * 8 + j + 1][pos] = (uint8_t)((pk >> 8) & 0xff);
+    }
+  }
+  __syncthreads();
+  // D rows x 64 B: 4 x 16 B chunks per row
+  for (int c = threadIdx.x; c < D * 4; c += 256) {
+    const int d = c >> 2, ch = c & 3;
+    const uint4 u = *reinterpret_cast<const uint4*>(&tile[d][ch * 16]);
+    *reinterpret_cast<uint4*>(out + b * ob + h * oh + (int64_t)d * od + blk * 64 + ch * 16) = u;
+  }
+}
+
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" size_t sage_quant_v_fp8_workspace_bytes(int B, int H, int N, int D) {
+  const size_t S = (size_t)(N + VQ_ROWS - 1) / VQ_ROWS;
+  return ((size_t)B * H * S * 3 * D + (size_t)B * H * 2 * D) * sizeof(float);
+}
+
+extern "C" int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D, const sage_tensor* v_fp8,
+                                float* v_scale, float* v_mean, float scale_max, void* workspace, sage_stream_t stream) {
+  if (!v || !v->data || !aligned16(v->data) || v->stride_b % 8 || v->stride_h % 8 || v->stride_n % 8) return SAGE_ERR_INVALID_ARGUMENT;
+  if (!v_fp8 || !v_fp8->data || !aligned16(v_fp8->data) || v_fp8->stride_b % 16 || v_fp8->stride_h % 16 || v_fp8->stride_n % 16)
+    return SAGE_ERR_INVALID_ARGUMENT;
+  if (!v_scale || !workspace || B <= 0 || H <= 0 || N <= 0 || !(scale_max > 0.f)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int S = (N + VQ_ROWS - 1) / VQ_ROWS;
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)B * H * S * 3 * D;
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t* vp = (const uint16_t*)v->data;
+  const dim3 g1(S, H, B), g2((N + 63) / 64, H, B);
+#define L1(DD, BF) hipLaunchKernelGGL((v_stats_partial_kernel<DD, BF>), g1, dim3(256), 0, st, vp, v->stride_b, v->stride_h, v->stride_n, N, part, S)
+#define L2(DD, BF)                                                                                                    \
+  hipLaunchKernelGGL((v_quant_transpose_kernel<DD, BF>), g2, dim3(256), 0, st, vp, v->stride_b, v->stride_h, v->stride_n, N, \
+                     coef, (uint8_t*)v_fp8->data, v_fp8->stride_b, v_fp8->stride_h, v_fp8->stride_n)
+  const bool bf = dtype == SAGE_BF16;
+  if (D == 64) { if (bf) L1(64, true); else L1(64, false); } else { if (bf) L1(128, true); else L1(128, false); }
+  hipLaunchKernelGGL(v_stats_final_kernel, dim3(B * H), dim3(128), 0, st, part, S, D, N, scale_max, v_mean ? 1 : 0, v_scale,
+                     v_mean, coef);
+  if (D == 64) { if (bf) L2(64, true); else L2(64, false); } else { if (bf) L2(128, true); else L2(128, false); }
+#undef L1
+#undef L2
+  return launch_status();
+}

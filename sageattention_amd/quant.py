@@ -86,9 +86,19 @@ def sub_mean(v: torch.Tensor, tensor_layout: str = "HND"):
     return out, vm
 
 
+def fp8_token_order() -> torch.Tensor:
+    """perm[pos] = token held at position ``pos`` of every 64-token block of the fp8 V^T tensor ("MFMA order",
+    csrc/sage_fp8.hip).  It plays the role of the reference's NVIDIA-fragment permutation (quant.py:234) for the
+    gfx950 PV MFMA; consumers other than this library's attention kernel must undo it."""
+    pos = torch.arange(64)
+    h, j = pos >> 5, pos & 31
+    return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h
+
+
 def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = True):
     """quant.py:225-322.  Returns (v_fp8 [B,H,D,ceil64(N)] (HND) / [B,D,H,ceil64(N)] (NHD) float8_e4m3fn (OCP, the
-    gfx950 MFMA format; the fork emits fnuz for gfx942), v_scale fp32 [B,H,D], vm fp32 [B,H,D] or None)."""
+    gfx950 MFMA format; the fork emits fnuz for gfx942) with the tokens of each 64-block in ``fp8_token_order()``,
+    v_scale fp32 [B,H,D], vm fp32 [B,H,D] or None)."""
     B, H, N, D = L.dims(v, tensor_layout)
     npad = (N + 63) // 64 * 64
     if tensor_layout == "HND":
