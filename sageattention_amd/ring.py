@@ -1,0 +1,164 @@
+"""Ring (sequence-parallel) SageAttention over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm).
+
+New component: the reference has no parallelism code of its own -- it only exposes ``return_lse`` for exactly this use
+(sageattention/core.py:122-124) and delegates ring/Ulysses to xDiT (example/parallel_sageattn_cogvideo.py:44-58).
+
+Scheme.  Rank r owns the query rows and the key/value rows of sequence shard r.  Every rank
+quantizes its OWN shard once (INT8 K with its local smoothing mean km_r, FP16 or FP8 V); the quantized shard plus
+km_r and the scales is one contiguous byte buffer that travels around the ring with one send/recv pair per step,
+double buffered, while the fused attention kernel runs on the shard that is already local.  Each step yields
+(o_s, lse_s) for KV shard s, where lse_s is the natural-log LSE of the true logits (the smooth-K correction
+(q.km_s)*sm_scale is applied per shard, core.py:651), and the partial results are merged with
+    lse = logaddexp(lse_a, lse_b);  o = o_a*exp(lse_a-lse) + o_b*exp(lse_b-lse).
+Causal: shards are contiguous in the sequence, so a shard from a later rank is skipped, the rank's own shard is
+causal, earlier shards are full attention.  Per step and rank the ring moves Hk*n*D bytes of K + 2*Hk*n*D (fp16 V)
+or Hk*n*D (fp8 V) over one xGMI link.
+"""
+from typing import Any, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import _qattn
+from .quant import _quant, k_mean, per_channel_fp8
+
+__all__ = ["ring_sageattn", "HipRingBackend"]
+
+
+class HipRingBackend:
+    """Device-side steps of the ring, all through the C ABI (include/sageattn_hip.h).  Tests substitute a CPU backend
+    with the same methods to exercise the ring protocol under gloo."""
+
+    def __init__(self, pv: str = "fp16", qk_quant_gran: str = "per_thread"):
+        assert pv in ("fp16", "fp8") and qk_quant_gran in ("per_warp", "per_thread")
+        self.pv, self.gran = pv, qk_quant_gran
+        self.code = L.GRAN_PER_THREAD if qk_quant_gran == "per_thread" else L.GRAN_PER_WARP
+        self.rnd = L.ROUND_TRITON if qk_quant_gran == "per_thread" else L.ROUND_CUDA
+
+    # -- queries: quantized once
+    def prepare_q(self, q, sm_scale):
+        gq = L.GRAN_PER_THREAD if self.gran == "per_thread" else L.GRAN_PER_WARP
+        q8, qs, _ = _quant(q, "HND", gq, False, 128, 32, 1.0, self.rnd)
+        return {"q": q, "q8": q8, "qs": qs, "sm_scale": sm_scale}
+
+    # -- local KV shard -> dict of tensors that travel (all contiguous)
+    def prepare_kv(self, k, v):
+        km = k_mean(k, "HND")
+        kg = L.GRAN_PER_THREAD if self.gran == "per_thread" else L.GRAN_PER_BLOCK
+        k8, ks, _ = _quant(k, "HND", kg, True, 64, 64, 1.0, self.rnd, mean=km)
+        parts = {"k8": k8.contiguous(), "ks": ks, "km": km}
+        if self.pv == "fp16":
+            parts["v"] = v.contiguous()
+        else:
+            v8, vsc, _ = per_channel_fp8(v, tensor_layout="HND", smooth_v=False)
+            parts["v"] = v8
+            parts["vs"] = vsc
+        return parts
+
+    def block_attn(self, qstate, kv, causal: bool):
+        """(o_blk [B,H,M,D] in q's dtype, lse [B,H,M] natural log of the true logits) for one KV shard."""
+        q, q8, qs, sm = qstate["q"], qstate["q8"], qstate["qs"], qstate["sm_scale"]
+        o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        if self.pv == "fp16":
+            lse2 = _qattn._attn_f16(q8, kv["k8"], kv["v"], o, qs, kv["ks"], None, 1, int(causal), self.code, sm, 1)
+        else:
+            lse2 = _qattn._attn_f8(q8, kv["k8"], kv["v"], o, qs, kv["ks"], kv["vs"], None, 1, int(causal), self.code, sm, 1)
+        # smooth-K correction of THIS shard: (q . km_s) * sm_scale   (core.py:613-617, 651)
+        g = q.shape[1] // kv["km"].shape[1]
+        km = kv["km"].repeat_interleave(g, dim=1) if g > 1 else kv["km"]
+        corr = torch.einsum("bhmd,bhd->bhm", q, km).float().contiguous()
+        lse = torch.empty_like(lse2)
+        L.check(L.lib().sage_finish_lse(lse2.data_ptr(), corr.data_ptr(), float(sm), lse.data_ptr(), lse2.numel(),
+                                        L.stream_ptr(q.device)), "sage_finish_lse")
+        return o, lse
+
+    def new_state(self, q):
+        B, H, M, D = q.shape
+        return (torch.zeros((B, H, M, D), dtype=torch.float32, device=q.device),
+                torch.full((B, H, M), float("-inf"), dtype=torch.float32, device=q.device))
+
+    def merge(self, state, o_blk, lse_blk):
+        o_acc, lse_acc = state
+        L.check(L.lib().sage_merge_attn_states(o_acc.data_ptr(), lse_acc.data_ptr(), o_blk.data_ptr(),
+                                               L.dtype_code(o_blk.dtype), lse_blk.data_ptr(), lse_acc.numel(),
+                                               o_acc.shape[-1], L.stream_ptr(o_acc.device)), "sage_merge_attn_states")
+        return state
+
+
+def _pack(parts):
+    """One contiguous uint8 buffer holding every travelling tensor (16-B aligned slots) + the views into it."""
+    names = sorted(parts)
+    sizes = [(parts[n].numel() * parts[n].element_size() + 255) // 256 * 256 for n in names]
+    dev = parts[names[0]].device
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    views, off = {}, 0
+    for n, sz in zip(names, sizes):
+        t = parts[n]
+        nb = t.numel() * t.element_size()
+        view = buf[off:off + nb].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        views[n] = view
+        off += sz
+    return buf, views
+
+
+def _views_like(buf, views):
+    out, off = {}, 0
+    for n in sorted(views):
+        t = views[n]
+        nb = t.numel() * t.element_size()
+        out[n] = buf[off:off + nb].view(t.dtype).view(t.shape)
+        off += (nb + 255) // 256 * 256
+    return out
+
+
+@torch.compiler.disable
+def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
+                  sm_scale: Optional[float] = None, group: Optional[dist.ProcessGroup] = None, pv: str = "fp16",
+                  qk_quant_gran: str = "per_thread", return_lse: bool = False, backend: Any = None, **kwargs: Any):
+    """SageAttention over a sequence sharded across the ranks of ``group`` (rank r holds rows [r*n, (r+1)*n) of q, k, v;
+    equal shard lengths).  Same tensor conventions as ``sageattn``; returns this rank's output rows (and their LSE)."""
+    if tensor_layout == "NHD":
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+    elif tensor_layout != "HND":
+        raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    D = q.size(-1)
+    if D not in (64, 128):
+        raise ValueError(f"ring_sageattn supports head_dim 64 or 128, got {D}")
+    if sm_scale is None:
+        sm_scale = D ** -0.5
+    be = backend if backend is not None else HipRingBackend(pv, qk_quant_gran)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    qstate = be.prepare_q(q, sm_scale)
+    cur_buf, cur = _pack(be.prepare_kv(k, v))
+    nxt_buf = torch.empty_like(cur_buf) if world > 1 else None
+    state = be.new_state(q)
+    nxt_rank = (rank + 1) % world
+    prv_rank = (rank - 1) % world
+    if world > 1 and group is not None:
+        nxt_rank, prv_rank = dist.get_global_rank(group, nxt_rank), dist.get_global_rank(group, prv_rank)
+
+    for step in range(world):
+        src = (rank - step) % world  # owner of the shard held in cur
+        reqs = []
+        if step + 1 < world:
+            # rotate while computing: send the shard we hold, receive the next one into the other buffer
+            ops = [dist.P2POp(dist.isend, cur_buf, nxt_rank, group), dist.P2POp(dist.irecv, nxt_buf, prv_rank, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        if not (is_causal and src > rank):
+            o_blk, lse_blk = be.block_attn(qstate, cur, is_causal and src == rank)
+            state = be.merge(state, o_blk, lse_blk)
+        for r in reqs:
+            r.wait()
+        if step + 1 < world:
+            cur_buf, nxt_buf = nxt_buf, cur_buf
+            cur = _views_like(cur_buf, cur)
+
+    o_acc, lse = state
+    o = o_acc.to(q.dtype)
+    if tensor_layout == "NHD":
+        o = o.transpose(1, 2)
+    return (o, lse) if return_lse else o

@@ -1,0 +1,53 @@
+"""CPU stand-in for sageattention_amd.ring.HipRingBackend, built on the oracle, so that the ring PROTOCOL (rotation,
+double buffering, causal skipping, LSE merge) can run under gloo without a GPU.  Test infrastructure only."""
+import torch
+
+from oracle import sage_oracle as O
+
+
+class OracleRingBackend:
+    def __init__(self, pv="fp16", qk_quant_gran="per_thread"):
+        self.pv, self.gran = pv, qk_quant_gran
+
+    def prepare_q(self, q, sm_scale):
+        if self.gran == "per_thread":
+            gid, n = O.gid_per_thread_q(q.shape[2])
+            q8, qs = O.quant_int8_grouped(q, gid, n, rounding="triton", scale_eps=1e-7)
+        else:
+            gid, n = O.gid_per_warp_q(q.shape[2], 128, 32)
+            q8, qs = O.quant_int8_grouped(q, gid, n, rounding="cuda")
+        return {"q": q, "q8": q8, "qs": qs, "sm_scale": sm_scale}
+
+    def prepare_kv(self, k, v):
+        km = O.k_mean(k, "HND")  # [B,H,1,D]
+        if self.gran == "per_thread":
+            gid, n = O.gid_per_thread_k(k.shape[2])
+            k8, ks = O.quant_int8_grouped(k, gid, n, mean=km, rounding="triton", scale_eps=1e-7)
+        else:
+            gid, n = O.gid_per_block(k.shape[2], 64)
+            k8, ks = O.quant_int8_grouped(k, gid, n, mean=km, rounding="cuda")
+        parts = {"k8": k8.contiguous(), "ks": ks, "km": km.squeeze(2).contiguous()}
+        if self.pv == "fp16":
+            parts["v"] = v.contiguous()
+        else:
+            v8, vs, _ = O.per_channel_fp8(v, "HND", smooth_v=False)
+            parts["v"], parts["vs"] = v8, vs
+        return parts
+
+    def block_attn(self, qstate, kv, causal):
+        q, q8, qs, sm = qstate["q"], qstate["q8"], qstate["qs"], qstate["sm_scale"]
+        M, N = q8.shape[2], kv["k8"].shape[2]
+        qrows = O.expand_q_scale(qs, M, self.gran)
+        kcols = O.expand_k_scale(kv["ks"], N, self.gran)
+        o, lse2 = O.attn_tile_loop(q8, kv["k8"], kv["v"], qrows, kcols, logit_mult=sm * O.LOG2E, is_causal=causal,
+                                   pv=self.pv, v_scale=kv.get("vs"), out_dtype=q.dtype)
+        corr = O.lse_correction(q, kv["km"], "HND")
+        return o, lse2 / O.LOG2E + corr * sm
+
+    def new_state(self, q):
+        B, H, M, D = q.shape
+        return torch.zeros(B, H, M, D), torch.full((B, H, M), float("-inf"))
+
+    def merge(self, state, o_blk, lse_blk):
+        o, l = O.merge_attn_states(state[0], state[1], o_blk, lse_blk)
+        return o, l

@@ -243,3 +243,44 @@ def test_full_size_properties(sa):
             assert (o[sl].cpu().float() - oo.float()).abs().max() < 0.04
         o8 = sa.sageattn_qk_int8_pv_fp8_cuda(q, k, ones)
         assert (o8.float() - 1).abs().max() < 0.08  # e4m3 P: the fp32 normaliser is not the sum of the rounded P
+
+
+@pytest.mark.parametrize("pv", ["fp16", "fp8"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_ring_steps_on_one_gpu(sa, pv, causal):
+    """The device half of ring attention (sageattention_amd/ring.py HipRingBackend: per-shard quantisation with the
+    local K mean, block attention with LSE, sage_merge_attn_states) run serially for 4 sequence shards on one GPU,
+    against exact fp32 attention over the whole sequence and against the single-device operator.  The communication
+    half is covered on CPU by tests/test_ring_gloo.py."""
+    from oracle import sage_oracle as O
+    from sageattention_amd.ring import HipRingBackend, ring_sageattn
+    torch.manual_seed(3)
+    B, Hq, Hk, N, D, P = 1, 8, 4, 1024, 128, 4
+    q = torch.randn(B, Hq, N, D, dtype=torch.float16, device="cuda")
+    k = (torch.randn(B, Hk, N, D, device="cuda") + 2 * torch.randn(1, Hk, 1, D, device="cuda")).half()
+    v = torch.randn(B, Hk, N, D, dtype=torch.float16, device="cuda")
+    be = HipRingBackend(pv=pv)
+    n = N // P
+    shards = [be.prepare_kv(k[:, :, r * n:(r + 1) * n], v[:, :, r * n:(r + 1) * n]) for r in range(P)]
+    outs, lses = [], []
+    for r in range(P):
+        qr = q[:, :, r * n:(r + 1) * n]
+        qs = be.prepare_q(qr, D ** -0.5)
+        st = be.new_state(qr)
+        for step in range(P):
+            src = (r - step) % P
+            if causal and src > r:
+                continue
+            ob, lb = be.block_attn(qs, shards[src], causal and src == r)
+            st = be.merge(st, ob, lb)
+        outs.append(st[0]); lses.append(st[1])
+    o = torch.cat(outs, dim=2).cpu()
+    lse = torch.cat(lses, dim=2).cpu()
+    ref, ref_lse = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=causal, return_lse=True)
+    assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
+    assert (lse - ref_lse).abs().max() < 0.06
+    # world_size 1 through the public entry point == one block
+    o1, l1 = ring_sageattn(q, k, v, is_causal=causal, pv=pv, return_lse=True)
+    assert (o1.cpu().float() - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert (l1.cpu() - ref_lse).abs().max() < 0.06
