@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--gran", default="per_thread", choices=["per_warp", "per_thread"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fa2", action="store_true")
+    ap.add_argument("--pv", default=None, choices=["fp16", "fp8"], help="override the PV precision of the workload")
+    ap.add_argument("--causal", default=None, type=int, choices=[0, 1], help="override the workload's causal flag")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
     args = ap.parse_args()
 
@@ -111,6 +113,8 @@ def main():
 
     wl = args.workload or ("c3" if world == 1 else "ring")
     B, H, N, D, causal, variant = WORKLOADS[wl]
+    variant = args.pv or variant
+    causal = bool(args.causal) if args.causal is not None else causal
     torch.manual_seed(0)
 
     if wl == "ring" and use_dist:
@@ -121,7 +125,7 @@ def main():
         v = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
 
         def step():
-            return ring.ring_sageattn(q, k, v, is_causal=causal)
+            return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant)
         parallelism = f"ring-sp{world}"
     else:
         q = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)

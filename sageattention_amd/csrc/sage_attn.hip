@@ -278,16 +278,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc_o[dt][e] = 0.f;
   float m_run = -1e30f;
-  float l_run = 0.f;  // fp8 path only: fp32 row sum of the UNROUNDED p, as the reference's fp8 kernel
-                      // (ComputeUnit::kCudaCore, sm89_*.cu:148, attn_utils.cuh:549-553)
-  // Row sums ride on the matrix pipe: l^T += ones(32x16) . P^T, every row of the 32x32 result is the same row sum
-  // of the ROUNDED fp16 P (as the reference: attn_utils.cuh:543-547 / mma.cuh:685-700 "rowsum via mma with ones").
-  v16f acc_l;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc_l[e] = 0.f;
-  v8h ones8;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
+  // per-lane partial row sum of the UNROUNDED p in fp32 on the VALU (the lane's 32 of the row's 64 keys per tile;
+  // the two lane halves are added once in the epilogue), as the reference's Triton kernels and its fp8 CUDA kernel
+  // (attn_qk_int8_per_block.py:55-60; ComputeUnit::kCudaCore, sm89_*.cu:148).  A ones-row MFMA that sums the
+  // rounded P (the reference's fp16 CUDA trick, attn_utils.cuh:543-547) was measured 3 % slower here: the chip is
+  // power limited and four extra 32x32x16 MFMAs per tile cost more clock than 32 v_add_f32.
+  float l_run = 0.f;
   // The int32 accumulator of S^T starts at the BIT PATTERN of 1.5*2^23: for |S| < 2^22 (|S| <= 128*127^2) the
   // accumulated integer, reinterpreted as fp32, IS the float 12582912 + S exactly, so the logit needs no
   // v_cvt_f32_i32: t - m = fma(as_float(acc), scale, -(12582912*scale + m)).
@@ -361,8 +357,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
       m_run = m_new;
       l_run *= alpha;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc_l[e] *= alpha;
-#pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[dt][e] *= alpha;
@@ -388,7 +382,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
       return pv;
     };
     if constexpr (!PV_FP8) {
-      // quarters of 16 keys, each followed by its PV MFMAs (and the ones-row MFMA that sums the rounded P)
+      // quarters of 16 keys, each followed by its PV MFMAs
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -400,8 +394,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
             const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
             pf[e] = ph[0];
             pf[e + 1] = ph[1];
+            l_run += pp[0];
+            l_run += pp[1];
           }
-          acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf, acc_l, 0, 0, 0);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const char* base = v_lds + vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D) + v_rd[dt];
@@ -526,8 +521,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
-  // fp16: the ones-row MFMA's k dimension spans both lane halves -> already the full row sum
-  const float l_tot = PV_FP8 ? swap_sum(l_run) : acc_l[0];
+  const float l_tot = swap_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (row < p.M) {
     uint16_t* op = p.o + b * p.osb + h * p.osh + (int64_t)row * p.osn;
