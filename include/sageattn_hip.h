@@ -170,6 +170,26 @@ int sage_attn_qk_int8_pv_f8(const sage_tensor* q8, const sage_tensor* k8, const 
                             int D, int is_causal, int qk_gran, int blkq, int warpq,
                             float sm_scale, int logit_mult_is_one, sage_stream_t stream);
 
+/* ---- packed variable-length sequences (sageattn_varlen, core.py:363-477) ------------------------
+ * q/k/v/o are packed [total_tokens, H, D] tensors described as sage_tensor with stride_b unused;
+ * sequence s owns rows [cu_seqlens[s], cu_seqlens[s+1]) (int32, device memory, num_seqs+1 entries).
+ * Quantization blocks restart at every sequence start (triton/quant_per_block_varlen.py:21-58); the
+ * scale tensors are [num_seqs, H, G(max_seqlen)] (a private layout: the reference's cumulative block
+ * offsets, quant_per_block_varlen.py:73-80, are not needed).  The mean vector is per (head, channel)
+ * over ALL packed tokens, [1,H,D] (core.py:461).  FP16 PV only and no LSE, as in the reference.
+ * Replace the Triton varlen quantizer + attn_qk_int8_block_varlen.py / attn_qk_int8_per_block_causal_varlen.py. */
+int sage_quant_qk_int8_varlen(const sage_tensor* x, int dtype, const int* cu_seqlens, int num_seqs, int H,
+                              int max_seqlen, int D, const void* mean, const sage_tensor* out, float* scale,
+                              int gran, int is_key, int blk, int warp, float mult, int rounding,
+                              sage_stream_t stream);
+int sage_attn_qk_int8_pv_f16_varlen(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v,
+                                    int v_dtype, const sage_tensor* o, int o_dtype,
+                                    const float* q_scale, const float* k_scale,
+                                    const int* cu_seqlens_q, const int* cu_seqlens_k, int num_seqs,
+                                    int Hq, int Hk, int max_seqlen_q, int max_seqlen_k, int D,
+                                    int is_causal, int qk_gran, int blkq, int warpq, float sm_scale,
+                                    int logit_mult_is_one, sage_stream_t stream);
+
 /* ---- ring attention merge (new; the reference only exposes return_lse, core.py:122-124) -------
  * In place: (o_acc, lse_acc) <- merge((o_acc, lse_acc), (o_blk, lse_blk)) with
  *   lse = logaddexp(lse_a, lse_b);  o = o_a*exp(lse_a-lse) + o_b*exp(lse_b-lse).

@@ -55,8 +55,35 @@ def run_quiet(fn, *a, **kw):
         return fn(*a, **kw)
 
 
+def gen_varlen():
+    """sageattn_varlen pairing (core.py:459-471): quant_per_block_varlen + attn_*_varlen."""
+    from sageattention.triton.quant_per_block_varlen import per_block_int8 as pbv
+    from sageattention.triton.attn_qk_int8_block_varlen import forward as attn_false_varlen
+    from sageattention.triton.attn_qk_int8_per_block_causal_varlen import forward as attn_true_varlen
+    torch.manual_seed(4242)
+    lens = [100, 37, 200, 64]
+    Hq, Hk, D = 4, 2, 64
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    T = sum(lens)
+    q = torch.randn(T, Hq, D).half()
+    k = (torch.randn(T, Hk, D) + 1.5 * torch.randn(1, Hk, D)).half()
+    v = torch.randn(T, Hk, D).half()
+    km = k.mean(dim=0, keepdim=True)      # core.py:461
+    k2 = k - km
+    sm = 1.0 / (D ** 0.5)
+    q8, qs, k8, ks, cuqs, cuks = pbv(q, k2, cu, cu, max(lens), max(lens), sm_scale=sm)
+    o = attn_false_varlen(q8, k8, v, cu, cu, max(lens), qs, ks, cuqs, cuks, output_dtype=torch.float16)
+    oc = attn_true_varlen(q8, k8, v, cu, cu, max(lens), qs, ks, cuqs, cuks, output_dtype=torch.float16)
+    path = os.path.join(OUT, "varlen", "varlen_d64.npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, q=bits(q), k=bits(k), v=bits(v), cu=cu.numpy(), q8=q8.numpy(), k8=k8.numpy(),
+                        qs=qs.numpy(), ks=ks.numpy(), o=bits(o), o_causal=bits(oc))
+    print(f"varlen_d64: wrote {os.path.getsize(path)/1024:.0f} KiB", flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    gen_varlen()
     for i, (name, B, Hq, Hk, M, N, D, layout, dt, causal, kbias) in enumerate(CASES):
         torch.manual_seed(1000 + i)
         dtype = torch.float16 if dt == "fp16" else torch.bfloat16

@@ -223,6 +223,55 @@ def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
                                         return_lse=return_lse, pv_accum_dtype="fp32")
 
 
-def sageattn_varlen(*args, **kwargs):
-    """Reference core.py:363-477.  Out of the round-1 hot-path scope."""
-    raise NotImplementedError("sageattn_varlen is not built yet on gfx950 (SURVEY.md 8f3)")
+@torch.compiler.disable
+def sageattn_varlen(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    cu_seqlens_q: torch.Tensor,
+    cu_seqlens_k: torch.Tensor,
+    max_seqlen_q: int,
+    max_seqlen_k: int,
+    is_causal: bool = False,
+    sm_scale: Optional[float] = None,
+    smooth_k: bool = True,
+    **kwargs: Any,
+) -> torch.Tensor:
+    """Packed variable-length SageAttention (reference core.py:363-477): q ``[cu_seqlens_q[-1], Hq, D]``, k/v
+    ``[cu_seqlens_k[-1], Hk, D]``; per-block INT8 Q/K (blocks restart at each sequence), FP16 PV; the K smoothing
+    mean is taken over ALL packed tokens (core.py:461).  The cumulative lengths stay on the device: no host sync."""
+    dtype = _common_checks(q, k, v)
+    assert cu_seqlens_q.is_contiguous() and cu_seqlens_k.is_contiguous(), "cu_seqlens_q and cu_seqlens_k must be contiguous."
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "q, k, v must be [total_tokens, heads, head_dim]"
+    with torch.cuda.device(q.device):
+        q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+        if sm_scale is None:
+            sm_scale = 1.0 / (head_dim_og ** 0.5)
+        Tq, Hq, D = q.shape
+        Tk, Hk, _ = k.shape
+        nseq = cu_seqlens_q.numel() - 1
+        cu_q = cu_seqlens_q.to(device=q.device, dtype=torch.int32)
+        cu_k = cu_seqlens_k.to(device=q.device, dtype=torch.int32)
+        lib, st = L.lib(), L.stream_ptr(q.device)
+        code = L.dtype_code(dtype)
+        # packed [T,H,D] == NHD with batch 1
+        km = k_mean(k.unsqueeze(0), "NHD") if smooth_k else None  # [1,Hk,D]
+
+        def desc3(t):
+            return L.SageTensor(t.data_ptr(), 0, t.stride(1), t.stride(0))
+        q8 = torch.empty(q.shape, dtype=torch.int8, device=q.device)
+        k8 = torch.empty(k.shape, dtype=torch.int8, device=q.device)
+        qs = torch.empty((nseq, Hq, (max_seqlen_q + 127) // 128), dtype=torch.float32, device=q.device)
+        ks = torch.empty((nseq, Hk, (max_seqlen_k + 63) // 64), dtype=torch.float32, device=q.device)
+        L.check(lib.sage_quant_qk_int8_varlen(desc3(q), code, cu_q.data_ptr(), nseq, Hq, int(max_seqlen_q), D, None,
+                                              desc3(q8), qs.data_ptr(), L.GRAN_PER_BLOCK, 0, 128, 128,
+                                              float(sm_scale * 1.44269504), L.ROUND_TRITON, st), "sage_quant_qk_int8_varlen")
+        L.check(lib.sage_quant_qk_int8_varlen(desc3(k), code, cu_k.data_ptr(), nseq, Hk, int(max_seqlen_k), D, L.ptr(km),
+                                              desc3(k8), ks.data_ptr(), L.GRAN_PER_BLOCK, 1, 64, 64, 1.0, L.ROUND_TRITON, st),
+                "sage_quant_qk_int8_varlen")
+        o = torch.empty(q.shape, dtype=dtype, device=q.device)
+        L.check(lib.sage_attn_qk_int8_pv_f16_varlen(desc3(q8), desc3(k8), desc3(v), code, desc3(o), code, qs.data_ptr(),
+                                                    ks.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), nseq, Hq, Hk,
+                                                    int(max_seqlen_q), int(max_seqlen_k), D, int(is_causal), L.GRAN_PER_BLOCK,
+                                                    128, 128, float(sm_scale), 1, st), "sage_attn_qk_int8_pv_f16_varlen")
+        return o[..., :head_dim_og]

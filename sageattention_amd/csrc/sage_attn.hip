@@ -35,6 +35,10 @@ struct AttnParams {
   int qgran, blkq, warpq;
   float logit_mult;
   int out_bf16;
+  // varlen (packed sequences, core.py:363-477): when cu_q/cu_k are set, "batch" b is sequence b, its rows are
+  // [cu[b], cu[b+1]) of the packed [total, H, D] tensors (stride_b unused) and p.M / p.N are the maximum lengths
+  const int* cu_q;
+  const int* cu_k;
 };
 
 __device__ __forceinline__ float swap_max(float x) {
@@ -146,6 +150,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   const int h = bh % p.Hq, b = bh / p.Hq;
   if constexpr (CAUSAL) qb = p.nqb - 1 - qb;  // heaviest blocks first
   const int hk = h / (p.Hq / p.Hk);
+  int M_ = p.M, N_ = p.N;
+  int64_t q_boff = b * p.qsb, k_boff = b * p.ksb, v_boff = b * p.vsb, o_boff = b * p.osb;
+  if (p.cu_q) {  // packed sequences: wave-uniform, before any barrier
+    const int q_lo = p.cu_q[b], k_lo = p.cu_k[b];
+    M_ = p.cu_q[b + 1] - q_lo;
+    N_ = p.cu_k[b + 1] - k_lo;
+    if (qb * QB >= M_ || N_ <= 0) return;
+    q_boff = (int64_t)q_lo * p.qsn; o_boff = (int64_t)q_lo * p.osn;
+    k_boff = (int64_t)k_lo * p.ksn; v_boff = (int64_t)k_lo * p.vsn;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,12 +167,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   const int r = lane & 31, hh = lane >> 5;
   const int q0 = qb * QB + wave * 32;
   const int row = q0 + r;
-  const int rowc = min(row, p.M - 1);
+  const int rowc = min(row, M_ - 1);
 
   // ---- Q^T fragments (B operand), resident for the whole kernel
   v4i qf[KS];
   {
-    const int8_t* qp = p.q + b * p.qsb + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
+    const int8_t* qp = p.q + q_boff + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qp + 32 * ks);
   }
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   const float* ksp = p.k_scale + ((int64_t)b * p.Hk + hk) * p.gk;
 
   // ---- tile range
-  const int kv_end = CAUSAL ? min(p.N, (qb + 1) * QB) : p.N;
+  const int kv_end = CAUSAL ? min(N_, (qb + 1) * QB) : N_;
   const int ntiles = (kv_end + 63) >> 6;
   const int wave_tiles = CAUSAL ? min(ntiles, ((q0 + 31) >> 6) + 1) : ntiles;
 
@@ -182,11 +196,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   //      per-thread byte offset is constant for the whole kernel and the tile advance is a scalar offset, so a
   //      tile costs no address VALU; rows >= N fall outside num_records and read as ZERO (V rows beyond the
   //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
-  const int8_t* kg = p.k + b * p.ksb + hk * p.ksh;
-  const uint8_t* vg = p.v + (b * p.vsb + hk * p.vsh) * (PV_FP8 ? 1 : 2);
-  const unsigned k_bytes = (unsigned)((int64_t)(p.N - 1) * p.ksn + D);
-  const unsigned v_bytes = PV_FP8 ? (unsigned)((int64_t)(D - 1) * p.vsn + ((p.N + 63) & ~63))
-                                  : (unsigned)(((int64_t)(p.N - 1) * p.vsn + D) * 2);
+  const int8_t* kg = p.k + k_boff + hk * p.ksh;
+  const uint8_t* vg = p.v + (v_boff + hk * p.vsh) * (PV_FP8 ? 1 : 2);
+  const unsigned k_bytes = (unsigned)((int64_t)(N_ - 1) * p.ksn + D);
+  const unsigned v_bytes = PV_FP8 ? (unsigned)((int64_t)(D - 1) * p.vsn + ((N_ + 63) & ~63))
+                                  : (unsigned)(((int64_t)(N_ - 1) * p.vsn + D) * 2);
   const v4i k_rsrc = make_rsrc(kg, k_bytes), v_rsrc_dma = make_rsrc(vg, v_bytes);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
   const int k_tile_stride = 64 * (int)p.ksn;                          // bytes per 64 keys
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        s[mt][e] = ((kv >= p.N) || (CAUSAL && kv > row)) ? kMaskedI : s[mt][e];
+        s[mt][e] = ((kv >= N_) || (CAUSAL && kv > row)) ? kMaskedI : s[mt][e];
       }
   };
   // row max of the logits of one tile, from the raw integers (scales are positive): v_max3_i32 + 1 cvt/group
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
 #endif
       if constexpr (MASKED) {
         const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        pv = ((kv >= p.N) || (CAUSAL && kv > row)) ? 0.f : pv;
+        pv = ((kv >= N_) || (CAUSAL && kv > row)) ? 0.f : pv;
       }
       return pv;
     };
@@ -449,10 +463,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   //   [wave_tiles, ntiles)  causal only: this wave is done but still stages tiles for its workgroup
   // Every wave executes the same number of barriers.
   int n_plain = wave_tiles;
-  if (p.N & 63) n_plain = min(n_plain, p.N >> 6);
+  if (N_ & 63) n_plain = min(n_plain, N_ >> 6);
   if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
   const int n_fast = max(0, min(n_plain - 1, wave_tiles - 1));
-  auto needs_mask = [&](const int j) { return ((j << 6) + 64 > p.N) || (CAUSAL && ((j << 6) + 63 > q0)); };
+  auto needs_mask = [&](const int j) { return ((j << 6) + 64 > N_) || (CAUSAL && ((j << 6) + 63 > q0)); };
 
   dma_k(0, 0);
   load_v(0, 0);
@@ -523,8 +537,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
   const float l_tot = swap_sum(l_run);
   const float inv = 1.0f / l_tot;
-  if (row < p.M) {
-    uint16_t* op = p.o + b * p.osb + h * p.osh + (int64_t)row * p.osn;
+  if (row < M_) {
+    uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row * p.osn;
     auto store_rows = [&](auto has_vm) __attribute__((always_inline)) {
       const float* vmp = p.v_mean + ((int64_t)b * p.Hk + hk) * D;
 #pragma unroll
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParam
         }
     };
     if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
-    if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * p.M + row] = m_run + log2f(l_tot) - kPOff;
+    if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * M_ + row] = m_run + log2f(l_tot) - kPOff;
   }
 }
 
@@ -593,7 +607,10 @@ int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
 static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
                     const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale, const float* v_scale,
                     const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal, int qk_gran,
-                    int blkq, int warpq, float sm_scale, int logit_mult_is_one, hipStream_t st) {
+                    int blkq, int warpq, float sm_scale, int logit_mult_is_one, hipStream_t st,
+                    const int* cu_q = nullptr, const int* cu_k = nullptr) {
+  if ((cu_q == nullptr) != (cu_k == nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (cu_q && (pv_fp8 || lse)) return SAGE_ERR_UNSUPPORTED;  // packed sequences: fp16 PV, no LSE (as the reference)
   if (!t_ok(q8, 16) || !t_ok(k8, 16) || !t_ok(v, pv_fp8 ? 16 : 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
   if (pv_fp8 && !v_scale) return SAGE_ERR_INVALID_ARGUMENT;
   if (B <= 0 || Hq <= 0 || Hk <= 0 || M <= 0 || N <= 0 || Hq % Hk != 0) return SAGE_ERR_INVALID_ARGUMENT;
@@ -623,6 +640,7 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.qgran = qk_gran; p.blkq = blkq; p.warpq = warpq;
   p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
   p.out_bf16 = o_dtype == SAGE_BF16;
+  p.cu_q = cu_q; p.cu_k = cu_k;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
   // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
   const int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
@@ -662,4 +680,15 @@ extern "C" int sage_attn_qk_int8_pv_f8(const sage_tensor* q8, const sage_tensor*
                                        int logit_mult_is_one, sage_stream_t stream) {
   return run_attn(q8, k8, v_fp8, true, SAGE_F16, o, o_dtype, q_scale, k_scale, v_scale, v_mean, lse, B, Hq, Hk, M, N, D,
                   is_causal, qk_gran, blkq, warpq, sm_scale, logit_mult_is_one, (hipStream_t)stream);
+}
+
+extern "C" int sage_attn_qk_int8_pv_f16_varlen(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, int v_dtype,
+                                               const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                               const int* cu_seqlens_q, const int* cu_seqlens_k, int num_seqs, int Hq, int Hk,
+                                               int max_seqlen_q, int max_seqlen_k, int D, int is_causal, int qk_gran, int blkq,
+                                               int warpq, float sm_scale, int logit_mult_is_one, sage_stream_t stream) {
+  if (!cu_seqlens_q || !cu_seqlens_k) return SAGE_ERR_INVALID_ARGUMENT;
+  return run_attn(q8, k8, v, false, v_dtype, o, o_dtype, q_scale, k_scale, nullptr, nullptr, nullptr, num_seqs, Hq, Hk,
+                  max_seqlen_q, max_seqlen_k, D, is_causal, qk_gran, blkq, warpq, sm_scale, logit_mult_is_one,
+                  (hipStream_t)stream, cu_seqlens_q, cu_seqlens_k);
 }

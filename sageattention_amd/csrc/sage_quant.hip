@@ -75,6 +75,7 @@ struct QuantParams {
   int warp;          // rows per warp group
   float mult;
   int rounding;
+  const int* cu;  // varlen: sequence b = rows [cu[b], cu[b+1]) of the packed tensor (stride_b unused); N = max length
 };
 
 __device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp) {
@@ -94,13 +95,23 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int H = gridDim.y;
   const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  int N_ = p.N;
+  int64_t x_boff = b * p.xsb, o_boff = b * p.osb;
+  if (p.cu) {
+    const int lo = p.cu[b];
+    N_ = p.cu[b + 1] - lo;
+    if (blk * BLK >= N_) return;  // uniform for the workgroup
+    x_boff = (int64_t)lo * p.xsn;
+    o_boff = (int64_t)lo * p.osn;
+  }
 
   __shared__ unsigned int gmax[64];
   if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
 
   float mean_f[8];
   if (p.mean) {
-    const uint4 um = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)b * H + h) * D + tc * 8);
+    // packed sequences share one mean over all tokens ([1,H,D], core.py:461)
+    const uint4 um = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)(p.cu ? 0 : b) * H + h) * D + tc * 8);
     unpack8<BF16>(um, mean_f);
   }
   float dvec[8];
@@ -110,14 +121,14 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
     unpack8<BF16>(ud, dvec);
   }
 
-  const uint16_t* xbase = p.x + b * p.xsb + h * p.xsh + tc * 8;
+  const uint16_t* xbase = p.x + x_boff + h * p.xsh + tc * 8;
   float xf[NP][8];
   uint4 raw[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int row = blk * BLK + i * RPP + tr;
     raw[i] = make_uint4(0, 0, 0, 0);
-    if (row < p.N) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xsn);
+    if (row < N_) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xsn);
   }
   __syncthreads();  // gmax zeroed
 
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   for (int i = 0; i < NP; ++i) {
     const int lr = i * RPP + tr;
     const int row = blk * BLK + lr;
-    const bool valid = row < p.N;
+    const bool valid = row < N_;
     unpack8<BF16>(raw[i], xf[i]);
     if (p.dot_vec) {
       float dot = 0.f;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
     p.scale[((int64_t)b * H + h) * p.G + blk * groups_per_blk + threadIdx.x] = sc;
   }
 
-  int8_t* obase = p.out + b * p.osb + h * p.osh + tc * 8;
+  int8_t* obase = p.out + o_boff + h * p.osh + tc * 8;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int lr = i * RPP + tr;
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
       w0 |= (uint32_t)(min(max(q[j], -128), 127) & 0xff) << (8 * j);
       w1 |= (uint32_t)(min(max(q[4 + j], -128), 127) & 0xff) << (8 * j);
     }
-    if (row < p.N) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.osn) = make_uint2(w0, w1);
+    if (row < N_) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.osn) = make_uint2(w0, w1);
   }
 }
 
@@ -275,10 +286,10 @@ extern "C" int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N,
   return launch_status();
 }
 
-extern "C" int sage_quant_qk_int8(const sage_tensor* x, int dtype, int B, int H, int N, int D, const void* mean,
-                                  const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
-                                  float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
-                                  sage_stream_t stream) {
+static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int D, const void* mean,
+                      const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
+                      float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
+                      sage_stream_t stream, const int* cu) {
   if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !scale || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
@@ -298,6 +309,7 @@ extern "C" int sage_quant_qk_int8(const sage_tensor* x, int dtype, int B, int H,
   p.mean = (const uint16_t*)mean;
   p.out = (int8_t*)out->data; p.osb = out->stride_b; p.osh = out->stride_h; p.osn = out->stride_n;
   p.scale = scale; p.dot_vec = (const uint16_t*)lse_dot_vec; p.dot_out = lse_dot; p.dot_group = dot_group > 0 ? dot_group : 1;
+  p.cu = cu;
   p.N = N; p.G = nblk * gpb; p.gran = gran; p.is_key = is_key ? 1 : 0; p.warp = warp; p.mult = mult; p.rounding = rounding;
   dim3 grid(nblk, H, B);
   hipStream_t st = (hipStream_t)stream;
@@ -308,6 +320,23 @@ extern "C" int sage_quant_qk_int8(const sage_tensor* x, int dtype, int B, int H,
 #undef BY_DT
 #undef LAUNCH
   return launch_status();
+}
+
+extern "C" int sage_quant_qk_int8(const sage_tensor* x, int dtype, int B, int H, int N, int D, const void* mean,
+                                  const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
+                                  float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
+                                  sage_stream_t stream) {
+  return quant_impl(x, dtype, B, H, N, D, mean, out, scale, gran, is_key, blk, warp, mult, rounding, lse_dot_vec, dot_group,
+                    lse_dot, stream, nullptr);
+}
+
+extern "C" int sage_quant_qk_int8_varlen(const sage_tensor* x, int dtype, const int* cu_seqlens, int num_seqs, int H,
+                                         int max_seqlen, int D, const void* mean, const sage_tensor* out, float* scale,
+                                         int gran, int is_key, int blk, int warp, float mult, int rounding,
+                                         sage_stream_t stream) {
+  if (!cu_seqlens) return SAGE_ERR_INVALID_ARGUMENT;
+  return quant_impl(x, dtype, num_seqs, H, max_seqlen, D, mean, out, scale, gran, is_key, blk, warp, mult, rounding, nullptr,
+                    1, nullptr, stream, cu_seqlens);
 }
 
 extern "C" int sage_sub_mean_f16(const sage_tensor* v, int dtype, int B, int H, int N, int D, const void* vm,
