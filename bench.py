@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-fa2", action="store_true")
     ap.add_argument("--pv", default=None, choices=["fp16", "fp8"], help="override the PV precision of the workload")
     ap.add_argument("--causal", default=None, type=int, choices=[0, 1], help="override the workload's causal flag")
+    ap.add_argument("--schedule", default="direct", choices=["direct", "ring"], help="N>1: KV exchange schedule")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
     args = ap.parse_args()
 
@@ -125,8 +126,8 @@ def main():
         v = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
 
         def step():
-            return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant)
-        parallelism = f"ring-sp{world}"
+            return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant, schedule=args.schedule)
+        parallelism = f"seq-parallel{world}-{args.schedule}"
     else:
         q = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
         k = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)

@@ -13,6 +13,15 @@ double buffered, while the fused attention kernel runs on the shard that is alre
 Causal: shards are contiguous in the sequence, so a shard from a later rank is skipped, the rank's own shard is
 causal, earlier shards are full attention.  Per step and rank the ring moves Hk*n*D bytes of K + 2*Hk*n*D (fp16 V)
 or Hk*n*D (fp8 V) over one xGMI link.
+
+Two exchange schedules, same arithmetic (results are bit-identical):
+  "ring"   P-1 rotation steps, each overlapped with one block of compute; one xGMI link per direction is busy.
+  "direct" the 8 GPUs of an MI355X node are fully connected by xGMI (7 links per GPU), so every rank posts its shard to
+           ALL peers at once (P-1 isend + P-1 irecv in one RCCL group), computes its local block meanwhile and then
+           consumes the peers' shards in ring order as they land: all 7 links carry traffic concurrently and the
+           exchange is paid once instead of P-1 times.  Costs P-1 receive buffers (C5: 7 x ~100 MB, trivial in 288 GB).
+At C5 (n = 8192 rows per rank, D = 128, 32 heads) one block is ~1.1 TFLOP (~0.85 ms) while a ring step moves ~100 MB
+over a single link (>1.3 ms): the ring would be communication bound, the direct schedule is not.  Default: "direct".
 """
 from typing import Any, Optional
 
@@ -116,13 +125,16 @@ def _views_like(buf, views):
 @torch.compiler.disable
 def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
                   sm_scale: Optional[float] = None, group: Optional[dist.ProcessGroup] = None, pv: str = "fp16",
-                  qk_quant_gran: str = "per_thread", return_lse: bool = False, backend: Any = None, **kwargs: Any):
+                  qk_quant_gran: str = "per_thread", return_lse: bool = False, backend: Any = None,
+                  schedule: str = "direct", **kwargs: Any):
     """SageAttention over a sequence sharded across the ranks of ``group`` (rank r holds rows [r*n, (r+1)*n) of q, k, v;
     equal shard lengths).  Same tensor conventions as ``sageattn``; returns this rank's output rows (and their LSE)."""
     if tensor_layout == "NHD":
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     elif tensor_layout != "HND":
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    if schedule not in ("ring", "direct"):
+        raise ValueError(f"Unknown schedule: {schedule}")
     D = q.size(-1)
     if D not in (64, 128):
         raise ValueError(f"ring_sageattn supports head_dim 64 or 128, got {D}")
@@ -132,30 +144,50 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
 
+    def peer(r):  # group rank -> global rank for P2POp
+        return dist.get_global_rank(group, r) if (world > 1 and group is not None) else r
+
     qstate = be.prepare_q(q, sm_scale)
     cur_buf, cur = _pack(be.prepare_kv(k, v))
-    nxt_buf = torch.empty_like(cur_buf) if world > 1 else None
     state = be.new_state(q)
-    nxt_rank = (rank + 1) % world
-    prv_rank = (rank - 1) % world
-    if world > 1 and group is not None:
-        nxt_rank, prv_rank = dist.get_global_rank(group, nxt_rank), dist.get_global_rank(group, prv_rank)
 
-    for step in range(world):
-        src = (rank - step) % world  # owner of the shard held in cur
-        reqs = []
-        if step + 1 < world:
-            # rotate while computing: send the shard we hold, receive the next one into the other buffer
-            ops = [dist.P2POp(dist.isend, cur_buf, nxt_rank, group), dist.P2POp(dist.irecv, nxt_buf, prv_rank, group)]
-            reqs = dist.batch_isend_irecv(ops)
-        if not (is_causal and src > rank):
-            o_blk, lse_blk = be.block_attn(qstate, cur, is_causal and src == rank)
-            state = be.merge(state, o_blk, lse_blk)
-        for r in reqs:
+    def consume(views, src):
+        nonlocal state
+        if is_causal and src > rank:
+            return
+        o_blk, lse_blk = be.block_attn(qstate, views, is_causal and src == rank)
+        state = be.merge(state, o_blk, lse_blk)
+
+    if schedule == "ring" or world == 1:
+        nxt_buf = torch.empty_like(cur_buf) if world > 1 else None
+        for step in range(world):
+            src = (rank - step) % world  # owner of the shard held in cur
+            reqs = []
+            if step + 1 < world:
+                # rotate while computing: send the shard we hold, receive the next one into the other buffer
+                ops = [dist.P2POp(dist.isend, cur_buf, peer((rank + 1) % world), group),
+                       dist.P2POp(dist.irecv, nxt_buf, peer((rank - 1) % world), group)]
+                reqs = dist.batch_isend_irecv(ops)
+            consume(cur, src)
+            for r in reqs:
+                r.wait()
+            if step + 1 < world:
+                cur_buf, nxt_buf = nxt_buf, cur_buf
+                cur = _views_like(cur_buf, cur)
+    else:
+        # direct exchange over the fully connected xGMI fabric: one send + one receive per peer, all posted at once
+        order = [(rank - s) % world for s in range(1, world)]  # same consumption order as the ring
+        rbufs = {src: torch.empty_like(cur_buf) for src in order}
+        need = [src for src in order if not (is_causal and src > rank)]          # shards this rank will use
+        wanted_by = [dst for dst in order if not (is_causal and rank > dst)]      # ranks that will use OUR shard
+        ops = [dist.P2POp(dist.isend, cur_buf, peer(dst), group) for dst in wanted_by]
+        ops += [dist.P2POp(dist.irecv, rbufs[src], peer(src), group) for src in need]
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        consume(cur, rank)
+        for r in reqs:  # RCCL completes the group as a whole; shards are consumed in ring order afterwards
             r.wait()
-        if step + 1 < world:
-            cur_buf, nxt_buf = nxt_buf, cur_buf
-            cur = _views_like(cur_buf, cur)
+        for src in need:
+            consume(_views_like(rbufs[src], cur), src)
 
     o_acc, lse = state
     o = o_acc.to(q.dtype)

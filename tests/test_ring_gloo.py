@@ -31,7 +31,7 @@ def _worker(rank, world, port, cfg, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from ring_cpu_backend import OracleRingBackend
     from sageattention_amd.ring import ring_sageattn
-    B, Hq, Hk, N, D, causal, pv, layout = cfg
+    B, Hq, Hk, N, D, causal, pv, layout, schedule = cfg
     q, k, v = _inputs(B, Hq, Hk, N, D)
     n = N // world
     sl = slice(rank * n, (rank + 1) * n)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, cfg, out_dir):
     if layout == "NHD":
         ql, kl, vl = (t.transpose(1, 2).contiguous() for t in (ql, kl, vl))
     o, lse = ring_sageattn(ql, kl, vl, tensor_layout=layout, is_causal=causal, return_lse=True,
-                           backend=OracleRingBackend(pv=pv))
+                           backend=OracleRingBackend(pv=pv), schedule=schedule)
     if layout == "NHD":
         o = o.transpose(1, 2)
     torch.save({"o": o.contiguous(), "lse": lse}, os.path.join(out_dir, f"r{rank}.pt"))
@@ -47,11 +47,12 @@ def _worker(rank, world, port, cfg, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,causal,pv,layout", [(2, False, "fp16", "HND"), (2, True, "fp16", "NHD"),
-                                                    (3, True, "fp8", "HND"), (2, False, "fp8", "HND")])
-def test_ring_matches_full_attention(tmp_path, world, causal, pv, layout):
+@pytest.mark.parametrize("world,causal,pv,layout,schedule", [
+    (2, False, "fp16", "HND", "ring"), (2, True, "fp16", "NHD", "ring"), (3, True, "fp8", "HND", "ring"),
+    (2, False, "fp8", "HND", "direct"), (3, True, "fp16", "NHD", "direct"), (4, False, "fp16", "HND", "direct")])
+def test_ring_matches_full_attention(tmp_path, world, causal, pv, layout, schedule):
     from oracle import sage_oracle as O
-    cfg = (1, 4, 2, 128 * world, 64, causal, pv, layout)
+    cfg = (1, 4, 2, 128 * world, 64, causal, pv, layout, schedule)
     mp.spawn(_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world, join=True)
     B, Hq, Hk, N, D = cfg[:5]
     q, k, v = _inputs(B, Hq, Hk, N, D)
