@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--pv", default=None, choices=["fp16", "fp8"], help="override the PV precision of the workload")
     ap.add_argument("--causal", default=None, type=int, choices=[0, 1], help="override the workload's causal flag")
     ap.add_argument("--schedule", default="direct", choices=["direct", "ring"], help="N>1: KV exchange schedule")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to "
+                    "rehearse the multi-process path with several ranks on ONE GPU")
+    ap.add_argument("--seq", type=int, default=None, help="override the workload's sequence length (rehearsals)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
     args = ap.parse_args()
 
@@ -98,6 +101,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -106,7 +111,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import sageattention_amd as sa
     from sageattention_amd import _lib as L, _qattn
@@ -115,6 +123,7 @@ def main():
     wl = args.workload or ("c3" if world == 1 else "ring")
     B, H, N, D, causal, variant = WORKLOADS[wl]
     variant = args.pv or variant
+    N = args.seq or N
     causal = bool(args.causal) if args.causal is not None else causal
     torch.manual_seed(0)
 
