@@ -17,7 +17,23 @@ SOURCES = [
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
 ]
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Rpass-analysis=kernel-resource-usage"]
+
+
+def _check_no_scratch(src, compiler_output):
+    """No kernel of this library may spill: the attention kernels issue their LDS-DMA from inline asm (invisible to
+    the compiler's s_waitcnt bookkeeping), which is only safe while the compiler adds no scratch traffic of its own,
+    and a spilling variant is a >3x performance cliff anyway.  Parsed from -Rpass-analysis=kernel-resource-usage."""
+    import re
+    name = None
+    for line in compiler_output.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and int(m.group(1)) != 0:
+            raise RuntimeError(f"{src}: kernel {name} uses {m.group(1)} bytes/lane of scratch (register spill)")
 
 
 def _stale(target, deps):
@@ -65,8 +81,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out)
+        _check_no_scratch(src, out)
+        if verbose:
+            print("\n".join(l for l in out.splitlines() if "remark:" not in l))
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

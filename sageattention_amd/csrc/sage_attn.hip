@@ -119,7 +119,10 @@ __device__ __forceinline__ int v_win_swz(int row) {
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
 template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8>
-__global__ __launch_bounds__(NWAVES * 64, 2) void attn_i8_kernel(const AttnParams p) {
+#ifndef SAGE_MINWAVES
+#define SAGE_MINWAVES 2
+#endif
+__global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(const AttnParams p) {
   static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
   constexpr int T = NWAVES * 64;
   constexpr int QB = NWAVES * 32;
