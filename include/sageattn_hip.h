@@ -170,6 +170,25 @@ int sage_attn_qk_int8_pv_f8(const sage_tensor* q8, const sage_tensor* k8, const 
                             int D, int is_causal, int qk_gran, int blkq, int warpq,
                             float sm_scale, int logit_mult_is_one, sage_stream_t stream);
 
+/* ---- fused attention with the Q quantizer folded into the kernel --------------------------------
+ * Same operators as sage_attn_qk_int8_pv_{f16,f8}, but `q` is the fp16/bf16 query tensor: each wave
+ * quantizes its own query rows in the kernel prologue with exactly the arithmetic of
+ * sage_quant_qk_int8 (qk_gran per_warp -> SAGE_ROUND_CUDA, per_thread -> SAGE_ROUND_TRITON, blk 128),
+ * which removes one launch and the int8 round trip of Q through HBM.  km (optional,
+ * [B,Hk,D], dtype of q): when given, `lse` receives the FINAL natural-log LSE
+ * lse2/log2(e) + (q.km)*sm_scale of core.py:651; otherwise lse2/log2(e).
+ * Replaces the pair {quant_per_warp_int8_cuda | per_thread_int8 (Q half), qk_int8_sv_*_attn}. */
+int sage_attn_fusedq_pv_f16(const sage_tensor* q, int q_dtype, const sage_tensor* k8, const sage_tensor* v,
+                            int v_dtype, const sage_tensor* o, int o_dtype, const float* k_scale,
+                            const void* km, const float* v_mean, float* lse, int B, int Hq, int Hk,
+                            int M, int N, int D, int is_causal, int qk_gran, int warpq, float sm_scale,
+                            sage_stream_t stream);
+int sage_attn_fusedq_pv_f8(const sage_tensor* q, int q_dtype, const sage_tensor* k8,
+                           const sage_tensor* v_fp8, const sage_tensor* o, int o_dtype,
+                           const float* k_scale, const void* km, const float* v_scale,
+                           const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D,
+                           int is_causal, int qk_gran, int warpq, float sm_scale, sage_stream_t stream);
+
 /* ---- packed variable-length sequences (sageattn_varlen, core.py:363-477) ------------------------
  * q/k/v/o are packed [total_tokens, H, D] tensors described as sage_tensor with stride_b unused;
  * sequence s owns rows [cu_seqlens[s], cu_seqlens[s+1]) (int32, device memory, num_seqs+1 entries).

@@ -79,6 +79,46 @@ def _finish_lse(lse2, corr, sm_scale):
 
 _GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_warp": L.GRAN_PER_WARP, "per_thread": L.GRAN_PER_THREAD}
 
+# Fold the Q quantizer into the attention kernel (sage_attn_fusedq_*): same bits, one launch and one pass over Q less.
+# Measured in-process (tools/ab_e2e.py): +2..4 % end to end at (4,32,2048,64), neutral at (4,32,8192,128) where the
+# per-workgroup prologue latency (one workgroup per CU) costs what the saved launch gains -> used for short sequences.
+FUSE_Q_QUANT = True
+FUSE_Q_MAX_SEQ = 4096
+
+
+def _quant_k(k, km, tensor_layout, qk_quant_gran):
+    """K half of core.py:621-624."""
+    if qk_quant_gran == "per_warp":
+        return _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km)[:2]
+    return _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km)[:2]
+
+
+def _fused_attn(q, k8, ks, v, o, km, v_scale, v_mean, tensor_layout, is_causal, qk_quant_gran, warpq, sm_scale, return_lse,
+                pv_fp8):
+    B, Hq, M, D = L.dims(q, tensor_layout)
+    _, Hk, N, _ = L.dims(k8, tensor_layout)
+    if Hq % Hk != 0:
+        raise ValueError(f"num_qo_heads ({Hq}) must be divisible by num_kv_heads ({Hk})")
+    lse = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device) if return_lse else None
+    lib, st = L.lib(), L.stream_ptr(q.device)
+    vm = v_mean.to(torch.float32).contiguous() if v_mean is not None else None
+    if pv_fp8:
+        vd = (L.SageTensor(v.data_ptr(), v.stride(0), v.stride(1), v.stride(2)) if tensor_layout == "HND"
+              else L.SageTensor(v.data_ptr(), v.stride(0), v.stride(2), v.stride(1)))
+        status = lib.sage_attn_fusedq_pv_f8(L.desc(q, tensor_layout), L.dtype_code(q.dtype), L.desc(k8, tensor_layout), vd,
+                                            L.desc(o, tensor_layout), L.dtype_code(o.dtype), ks.data_ptr(), L.ptr(km),
+                                            v_scale.data_ptr(), L.ptr(vm), L.ptr(lse), B, Hq, Hk, M, N, D, int(is_causal),
+                                            _GRAN_CODE[qk_quant_gran], warpq, float(sm_scale), st)
+        L.check(status, "sage_attn_fusedq_pv_f8")
+    else:
+        status = lib.sage_attn_fusedq_pv_f16(L.desc(q, tensor_layout), L.dtype_code(q.dtype), L.desc(k8, tensor_layout),
+                                             L.desc(v, tensor_layout), L.dtype_code(v.dtype), L.desc(o, tensor_layout),
+                                             L.dtype_code(o.dtype), ks.data_ptr(), L.ptr(km), L.ptr(vm), L.ptr(lse),
+                                             B, Hq, Hk, M, N, D, int(is_causal), _GRAN_CODE[qk_quant_gran], warpq,
+                                             float(sm_scale), st)
+        L.check(status, "sage_attn_fusedq_pv_f16")
+    return lse
+
 
 def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smooth_k, smooth_v, return_lse, WARPQ=32):
     dtype = q.dtype
@@ -89,11 +129,17 @@ def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smoot
         _, Hq, _, _ = L.dims(q, tensor_layout)
         _, Hk, _, _ = L.dims(k, tensor_layout)
         km = k_mean(k, tensor_layout) if smooth_k else None
-        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, return_lse, Hq, Hk)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         vm = None
         if smooth_v:
             v, vm = sub_mean(v, tensor_layout)
+        if FUSE_Q_QUANT and qk_quant_gran != "per_block" and L.dims(q, tensor_layout)[2] <= FUSE_Q_MAX_SEQ:
+            k8, ks = _quant_k(k, km, tensor_layout, qk_quant_gran)
+            lse = _fused_attn(q, k8, ks, v, o, km, None, vm, tensor_layout, is_causal, qk_quant_gran, WARPQ, sm_scale,
+                              return_lse, False)
+            o = o[..., :head_dim_og]
+            return (o, lse) if return_lse else o
+        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, return_lse, Hq, Hk)
         lse2 = _qattn._attn_f16(q8, k8, v, o, qs, ks, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
                                 _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse),
                                 logit_mult_is_one=(qk_quant_gran == "per_block"))
@@ -192,9 +238,15 @@ def sageattn_qk_int8_pv_fp8_cuda(
         _, Hq, _, _ = L.dims(q, tensor_layout)
         _, Hk, _, _ = L.dims(k, tensor_layout)
         km = k_mean(k, tensor_layout) if smooth_k else None
-        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, 32, return_lse, Hq, Hk)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         v8, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+        if FUSE_Q_QUANT and L.dims(q, tensor_layout)[2] <= FUSE_Q_MAX_SEQ:
+            k8, ks = _quant_k(k, km, tensor_layout, qk_quant_gran)
+            lse = _fused_attn(q, k8, ks, v8, o, km, v_scale, vm, tensor_layout, is_causal, qk_quant_gran, 32, sm_scale,
+                              return_lse, True)
+            o = o[..., :head_dim_og]
+            return (o, lse) if return_lse else o
+        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, 32, return_lse, Hq, Hk)
         lse2 = _qattn._attn_f8(q8, k8, v8, o, qs, ks, v_scale, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
                                _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse))
         o = o[..., :head_dim_og]

@@ -39,6 +39,13 @@ struct AttnParams {
   // [cu[b], cu[b+1]) of the packed [total, H, D] tensors (stride_b unused) and p.M / p.N are the maximum lengths
   const int* cu_q;
   const int* cu_k;
+  // fused Q quantizer: when q_f16 is set, q/q_scale are ignored and every wave quantizes its own 32 query rows in the
+  // prologue (per_warp: CUDA numerics, per_thread: Triton numerics -- the pairings of core.py:621-624); km (optional,
+  // [B,Hk,D] in q's dtype) yields the LSE correction q.km and lse then receives the FINAL natural-log LSE (core.py:651)
+  const uint16_t* q_f16;
+  const uint16_t* km;
+  int q_bf16;
+  float sm_scale;
 };
 
 __device__ __forceinline__ float swap_max(float x) {
@@ -172,21 +179,108 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   const int row = q0 + r;
   const int rowc = min(row, M_ - 1);
 
-  // ---- Q^T fragments (B operand), resident for the whole kernel
+  // ---- Q^T fragments (B operand), resident for the whole kernel, and the per-row q scale
   v4i qf[KS];
-  {
+  float qsc;
+  float lse_corr = 0.f;
+  if (p.q_f16 == nullptr) {
     const int8_t* qp = p.q + q_boff + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const v4i*>(qp + 32 * ks);
-  }
-  // ---- per-row q scale (…sm80.cu:103-117 index maps, evaluated once per lane)
-  float qsc;
-  {
-    int qi;
+    int qi;  // …sm80.cu:103-117 index maps, evaluated once per lane
     if (p.qgran == SAGE_GRAN_PER_BLOCK) qi = rowc / p.blkq;
     else if (p.qgran == SAGE_GRAN_PER_WARP) qi = rowc / p.warpq;
     else qi = (rowc / p.warpq) * 8 + (rowc & 7);
     qsc = p.q_scale[((int64_t)b * p.Hq + h) * p.gq + qi] * p.logit_mult;
+  } else {
+    // Fused Q quantizer (replaces one launch of K1 and the q8 round trip through HBM).  Lane (r, hh) owns the 16-column
+    // chunks [32*ks + 16*hh, +16) of its row: exactly the bytes of its B fragments.  Same arithmetic as K1, so q8 and
+    // the scales are bit-identical to the stand-alone quantizer; rows >= M are zeros, as there.
+    const bool valid = row < M_;
+    const uint16_t* qp = p.q_f16 + q_boff + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
+    uint4 raw[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      raw[ks][0] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
+      raw[ks][1] = *reinterpret_cast<const uint4*>(qp + 32 * ks + 8);
+    }
+    auto unpack = [&](const uint4& u, float (&f)[8]) __attribute__((always_inline)) {
+      if (p.q_bf16) unpack8<true>(u, f); else unpack8<false>(u, f);
+      if (!valid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      }
+    };
+    float amax = 0.f, dot = 0.f;
+    const uint16_t* kmp = p.km ? p.km + ((int64_t)b * p.Hk + hk) * D + 16 * hh : nullptr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float f[8];
+        unpack(raw[ks][c], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+        if (kmp) {
+          float g[8];
+          const uint4 uk = *reinterpret_cast<const uint4*>(kmp + 32 * ks + 8 * c);
+          if (p.q_bf16) unpack8<true>(uk, g); else unpack8<false>(uk, g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dot += f[e] * g[e];
+        }
+      }
+    amax = swap_max(amax);  // the other half of the row
+    lse_corr = swap_sum(dot);
+    const bool triton = p.qgran == SAGE_GRAN_PER_THREAD;
+    if (triton) {  // rows with equal r % 8 inside the 32-row block (quant_per_thread.py:27-36)
+      amax = fmaxf(amax, __shfl_xor(amax, 8));
+      amax = fmaxf(amax, __shfl_xor(amax, 16));
+    } else {       // per warp: warpq rows (16 or 32) share a scale (fused.cu:746-750)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+      if (p.warpq == 32) amax = fmaxf(amax, __shfl_xor(amax, 16));
+    }
+    const float a_c = fmaxf(amax, 0.0000001f);
+    const float sc = triton ? amax / 127.f + 0.0000001f : a_c / 127.f;
+    const float inv = 127.f / a_c;
+    const float rcp_sc = 1.0f / sc;
+    // Triton numerics need x/sc correctly rounded before the half-away rounding; as in K1 the reciprocal product is
+    // used unless some value of the wave lands within 2^-14 of a rounding boundary (then the exact division decides)
+    auto quantize = [&](const bool exact) __attribute__((always_inline)) -> bool {
+      bool near = false;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float f[8];
+          unpack(raw[ks][c], f);
+          int qv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (triton) {
+              float y = exact ? f[e] / sc : f[e] * rcp_sc;  // IEEE division (quant_per_thread.py:41) / fast path
+              if (!exact) {
+                const float z = fabsf(y) + 0.5f;
+                const float fr = z - floorf(z);
+                near |= (fr < 6.1035156e-5f) | (fr > 1.0f - 6.1035156e-5f);
+              }
+              y = y + (y >= 0.f ? 0.5f : -0.5f);
+              qv[e] = (int)y;
+            } else {
+              qv[e] = (int)rintf(f[e] * inv);  // cvt.rni (fused.cu:176-181)
+            }
+            qv[e] = min(max(qv[e], -128), 127) & 0xff;
+          }
+          w[2 * c] = (uint32_t)qv[0] | ((uint32_t)qv[1] << 8) | ((uint32_t)qv[2] << 16) | ((uint32_t)qv[3] << 24);
+          w[2 * c + 1] = (uint32_t)qv[4] | ((uint32_t)qv[5] << 8) | ((uint32_t)qv[6] << 16) | ((uint32_t)qv[7] << 24);
+        }
+        qf[ks][0] = (int)w[0]; qf[ks][1] = (int)w[1]; qf[ks][2] = (int)w[2]; qf[ks][3] = (int)w[3];
+      }
+      return near || !(fabsf(rcp_sc) < 3.0e38f);
+    };
+    if (__builtin_amdgcn_ballot_w64(quantize(false) && triton) != 0) (void)quantize(true);
+    qsc = sc * p.logit_mult;
   }
   const float* ksp = p.k_scale + ((int64_t)b * p.Hk + hk) * p.gk;
 
@@ -572,7 +666,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         }
     };
     if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
-    if (p.lse && hh == 0) p.lse[((int64_t)b * p.Hq + h) * M_ + row] = m_run + log2f(l_tot) - kPOff;
+    if (p.lse && hh == 0) {
+      const float lse2 = m_run + log2f(l_tot) - kPOff;  // base 2, scaled + smoothed logits (…sm80.cu:657-668)
+      p.lse[((int64_t)b * p.Hq + h) * M_ + row] = p.q_f16 ? lse2 / 1.44269504f + lse_corr * p.sm_scale : lse2;
+    }
   }
 }
 
@@ -611,10 +708,17 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
                     const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale, const float* v_scale,
                     const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal, int qk_gran,
                     int blkq, int warpq, float sm_scale, int logit_mult_is_one, hipStream_t st,
-                    const int* cu_q = nullptr, const int* cu_k = nullptr) {
+                    const int* cu_q = nullptr, const int* cu_k = nullptr, int q_dtype = -1, const void* km = nullptr) {
+  const bool fusedq = q_dtype >= 0;  // q8 is then the fp16/bf16 query tensor
   if ((cu_q == nullptr) != (cu_k == nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (fusedq) {
+    if (q_dtype != SAGE_F16 && q_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+    if (qk_gran == SAGE_GRAN_PER_BLOCK || cu_q || (km && !aligned16(km))) return SAGE_ERR_UNSUPPORTED;
+    if (!t_ok(q8, 8) || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
+    q_scale = k_scale;  // unused placeholder so the shared checks below pass
+  }
   if (cu_q && (pv_fp8 || lse)) return SAGE_ERR_UNSUPPORTED;  // packed sequences: fp16 PV, no LSE (as the reference)
-  if (!t_ok(q8, 16) || !t_ok(k8, 16) || !t_ok(v, pv_fp8 ? 16 : 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
+  if (!t_ok(q8, fusedq ? 8 : 16) || !t_ok(k8, 16) || !t_ok(v, pv_fp8 ? 16 : 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
   if (pv_fp8 && !v_scale) return SAGE_ERR_INVALID_ARGUMENT;
   if (B <= 0 || Hq <= 0 || Hk <= 0 || M <= 0 || N <= 0 || Hq % Hk != 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
@@ -644,6 +748,8 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
   p.out_bf16 = o_dtype == SAGE_BF16;
   p.cu_q = cu_q; p.cu_k = cu_k;
+  p.q_f16 = fusedq ? (const uint16_t*)q8->data : nullptr;
+  p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
   // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
   const int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
@@ -694,4 +800,23 @@ extern "C" int sage_attn_qk_int8_pv_f16_varlen(const sage_tensor* q8, const sage
   return run_attn(q8, k8, v, false, v_dtype, o, o_dtype, q_scale, k_scale, nullptr, nullptr, nullptr, num_seqs, Hq, Hk,
                   max_seqlen_q, max_seqlen_k, D, is_causal, qk_gran, blkq, warpq, sm_scale, logit_mult_is_one,
                   (hipStream_t)stream, cu_seqlens_q, cu_seqlens_k);
+}
+
+extern "C" int sage_attn_fusedq_pv_f16(const sage_tensor* q, int q_dtype, const sage_tensor* k8, const sage_tensor* v, int v_dtype,
+                                       const sage_tensor* o, int o_dtype, const float* k_scale, const void* km,
+                                       const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D,
+                                       int is_causal, int qk_gran, int warpq, float sm_scale, sage_stream_t stream) {
+  if (q_dtype != SAGE_F16 && q_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  return run_attn(q, k8, v, false, v_dtype, o, o_dtype, nullptr, k_scale, nullptr, v_mean, lse, B, Hq, Hk, M, N, D, is_causal,
+                  qk_gran, 128, warpq, sm_scale, 0, (hipStream_t)stream, nullptr, nullptr, q_dtype, km);
+}
+
+extern "C" int sage_attn_fusedq_pv_f8(const sage_tensor* q, int q_dtype, const sage_tensor* k8, const sage_tensor* v_fp8,
+                                      const sage_tensor* o, int o_dtype, const float* k_scale, const void* km,
+                                      const float* v_scale, const float* v_mean, float* lse, int B, int Hq, int Hk, int M,
+                                      int N, int D, int is_causal, int qk_gran, int warpq, float sm_scale,
+                                      sage_stream_t stream) {
+  if (q_dtype != SAGE_F16 && q_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  return run_attn(q, k8, v_fp8, true, SAGE_F16, o, o_dtype, nullptr, k_scale, v_scale, v_mean, lse, B, Hq, Hk, M, N, D,
+                  is_causal, qk_gran, 128, warpq, sm_scale, 0, (hipStream_t)stream, nullptr, nullptr, q_dtype, km);
 }

@@ -324,3 +324,25 @@ def test_edge_shapes_vs_oracle(sa, shape, pv, nwaves):
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
     assert (o.cpu().float() - oo.float()).abs().max() < (2e-3 if pv == "fp16" else 0.06)
     assert (lse.cpu() - ol).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("gran", ["per_warp", "per_thread"])
+@pytest.mark.parametrize("pv", ["fp16", "fp8"])
+def test_fused_q_quantizer_is_bit_identical(sa, golden, gran, pv):
+    """The Q quantizer folded into the attention kernel (sage_attn_fusedq_*) uses the arithmetic of the stand-alone
+    quantizer K1: outputs must be BIT-identical to the two-kernel path; the fused LSE (final, natural log) matches the
+    unfused one to 1e-5 (the q.km dot is summed in a different order)."""
+    from sageattention_amd import core
+    g, m = golden, golden.meta
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    kw = dict(tensor_layout=m["layout"], is_causal=bool(m["causal"]), qk_quant_gran=gran, return_lse=True, pv_accum_dtype="fp32")
+    assert core.FUSE_Q_QUANT and m["M"] <= core.FUSE_Q_MAX_SEQ
+    o1, l1 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
+    core.FUSE_Q_QUANT = False
+    try:
+        o0, l0 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
+    finally:
+        core.FUSE_Q_QUANT = True
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o0), (o1.float() - o0.float()).abs().max()
+    assert (l1 - l0).abs().max() < 1e-5 * max(1.0, float(l0.abs().max()))

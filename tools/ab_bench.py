@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--wl", default="c3")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--data", default="randn", choices=["randn", "zeros"], help="zeros: DVFS probe (cdna guide rule 25)")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
@@ -21,6 +22,8 @@ torch.manual_seed(0)
 q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
 k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
 v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+if a.data == "zeros":
+    q.zero_(); k.zero_(); v.zero_()
 km = sa.quant.k_mean(k)
 q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
 o = torch.empty_like(q)
