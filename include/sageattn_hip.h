@@ -189,6 +189,21 @@ int sage_attn_fusedq_pv_f8(const sage_tensor* q, int q_dtype, const sage_tensor*
                            const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D,
                            int is_causal, int qk_gran, int warpq, float sm_scale, sage_stream_t stream);
 
+/* ---- attention with an explicit attn_mask ----------------------------------------------------------
+ * The attn_mask argument of sageattn_qk_int8_pv_fp16_triton (core.py:249-251,306-318; kernels
+ * triton/attn_qk_int8_per_block.py:33-52, attn_qk_int8_per_thread.py:37-75).  Non-causal, FP16 PV.
+ * attn_mask: device pointer to a [B,Hq,M,N] VIEW given by mask_strides[4] in ELEMENTS (host array; 0 =
+ * broadcast dimension).  mask_kind 1: bool/uint8, zero = masked (the reference adds -1e6 to the base-2
+ * logit); 2: fp16, 3: bf16 additive mask, added to the base-2 logit exactly as the reference does (after
+ * its sm_scale*log2(e) scaling).  Rows without any allowed key are undefined in the reference (they
+ * depend on its 128x64 tile skipping) and here. */
+int sage_attn_qk_int8_pv_f16_masked(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v,
+                                    int v_dtype, const sage_tensor* o, int o_dtype,
+                                    const float* q_scale, const float* k_scale, const void* attn_mask,
+                                    int mask_kind, const int64_t* mask_strides, float* lse, int B, int Hq,
+                                    int Hk, int M, int N, int D, int qk_gran, int blkq, int warpq,
+                                    float sm_scale, int logit_mult_is_one, sage_stream_t stream);
+
 /* ---- packed variable-length sequences (sageattn_varlen, core.py:363-477) ------------------------
  * q/k/v/o are packed [total_tokens, H, D] tensors described as sage_tensor with stride_b unused;
  * sequence s owns rows [cu_seqlens[s], cu_seqlens[s+1]) (int32, device memory, num_seqs+1 entries).

@@ -81,9 +81,36 @@ def gen_varlen():
     print(f"varlen_d64: wrote {os.path.getsize(path)/1024:.0f} KiB", flush=True)
 
 
+def gen_masked():
+    """attn_mask pairing of sageattn_qk_int8_pv_fp16_triton (core.py:306-318, upstream per-block pairing):
+    bool mask (False -> -1e6, all-False tiles skipped) and additive mask in q's dtype."""
+    torch.manual_seed(777)
+    B, H, M, N, D = 1, 2, 200, 300, 64
+    q = torch.randn(B, H, M, D).half()
+    k = torch.randn(B, H, N, D).half()
+    v = torch.randn(B, H, N, D).half()
+    km = k.mean(dim=2, keepdim=True)
+    sm = 1.0 / (D ** 0.5)
+    qb, qsb, kb, ksb = per_block_int8(q, k, km=km, sm_scale=sm, tensor_layout="HND")
+    mb = torch.rand(1, 1, M, N) > 0.3
+    mb[..., :128, 64:192] = False            # whole 128x64 tiles masked out (tile skipping)
+    mb[..., 5, :] = False                    # a fully masked row
+    mb = mb.expand(B, H, M, N)
+    mf = (torch.randn(B, 1, M, N) * 2).half().expand(B, H, M, N)
+    ob, lb = attn_block(qb, kb, v, qsb, ksb, tensor_layout="HND", attn_mask=mb, output_dtype=torch.float16, return_lse=True)
+    of, lf = attn_block(qb, kb, v, qsb, ksb, tensor_layout="HND", attn_mask=mf, output_dtype=torch.float16, return_lse=True)
+    path = os.path.join(OUT, "masked", "masked_d64.npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, q=bits(q), k=bits(k), v=bits(v), km=bits(km), q8=qb.numpy(), k8=kb.numpy(), qs=qsb.numpy(),
+                        ks=ksb.numpy(), mask_bool=mb[0, 0].numpy(), mask_float=bits(mf[:, 0].contiguous()),
+                        o_bool=bits(ob), lse2_bool=lb.numpy(), o_float=bits(of), lse2_float=lf.numpy())
+    print(f"masked_d64: wrote {os.path.getsize(path)/1024:.0f} KiB", flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     gen_varlen()
+    gen_masked()
     for i, (name, B, Hq, Hk, M, N, D, layout, dt, causal, kbias) in enumerate(CASES):
         torch.manual_seed(1000 + i)
         dtype = torch.float16 if dt == "fp16" else torch.bfloat16

@@ -81,7 +81,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        _check_no_scratch(src, out)
+        try:
+            _check_no_scratch(src, out)
+        except RuntimeError:
+            os.remove(os.path.join(CSRC, src.replace(".hip", ".o")))  # never link (or cache) a spilling object
+            raise
         if verbose:
             print("\n".join(l for l in out.splitlines() if "remark:" not in l))
     if force or procs or _stale(LIB, objs):

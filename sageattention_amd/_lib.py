@@ -51,6 +51,9 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "sage_attn_fusedq_pv_f8": (c_int, [_P, c_int, _P, _P, _P, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "sage_attn_qk_int8_pv_f16_masked": (c_int, [_P, _P, _P, c_int, _P, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                                ctypes.POINTER(c_int64), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "sage_merge_attn_states": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "sage_finish_lse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sage_set_tuning": (c_int, [c_int, c_int]),

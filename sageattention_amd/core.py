@@ -6,6 +6,7 @@ Same public names, arguments, defaults, return values and error behaviour as the
 argument handling runs as hand-written HIP through the C ABI (include/sageattn_hip.h): K mean, INT8 quantizers
 (with the LSE correction fused), V fp16/fp8 preparation and the fused attention kernel.  No Triton, no
 rocWMMA, no debug dumps (the fork's torch.save side effects, core.py:320-352,845-881, are not reproduced)."""
+import ctypes
 import warnings
 from typing import Any, Optional
 
@@ -197,13 +198,45 @@ def sageattn_qk_int8_pv_fp16_triton(
     **kwargs: Any,
 ) -> torch.Tensor:
     """Reference core.py:161-360 (per-block INT8, FP16 PV).  Same numerics contract, served by the HIP kernels:
-    per-block quantization with sm_scale*log2e folded into Q.  ``attn_mask`` is a SURVEY 8(f2) "next" item."""
-    _common_checks(q, k, v)
-    if attn_mask is not None:
-        raise NotImplementedError("attn_mask is not supported by the gfx950 kernels yet (SURVEY.md 8f2)")
+    per-block quantization with sm_scale*log2e folded into Q.  ``attn_mask`` (bool, or additive in q's dtype; any shape
+    broadcastable to [B,H,M,N]) follows the reference kernels: False adds -1e6, an additive mask is added to the
+    base-2 logits (attn_qk_int8_per_block.py:33-52)."""
+    dtype = _common_checks(q, k, v)
     if quantization_backend not in ("triton", "cuda"):
         raise ValueError(f"Unsupported quantization backend: {quantization_backend}")
-    return _sage_fp16(q, k, v, tensor_layout, is_causal, "per_block", sm_scale, smooth_k, False, return_lse)
+    if attn_mask is None:
+        return _sage_fp16(q, k, v, tensor_layout, is_causal, "per_block", sm_scale, smooth_k, False, return_lse)
+    # ---- attn_mask (core.py:249-251, 302-318)
+    assert attn_mask.dtype == torch.bool or attn_mask.dtype == q.dtype, "attn_mask must be of dtype bool or the same dtype as q."
+    assert attn_mask.device == q.device, "All tensors must be on the same device."
+    assert not is_causal, "Mask should be None for causal attention."
+    with torch.cuda.device(q.device):
+        q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+        if sm_scale is None:
+            sm_scale = 1.0 / (head_dim_og ** 0.5)
+        B, Hq, M, D = L.dims(q, tensor_layout)
+        _, Hk, N, _ = L.dims(k, tensor_layout)
+        try:
+            attn_mask = attn_mask.expand((B, Hq, M, N))
+        except Exception:
+            raise AssertionError(f"attn_mask shape {attn_mask.shape} cannot be broadcast to {(B, Hq, M, N)}")
+        if v.dtype != torch.float16:
+            v = v.to(torch.float16)  # core.py:289-290
+        km = k_mean(k, tensor_layout) if smooth_k else None
+        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, "per_block", sm_scale, 32, return_lse, Hq, Hk)
+        o = torch.empty(q.size(), dtype=dtype, device=q.device)
+        lse2 = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device) if return_lse else None
+        kind = 1 if attn_mask.dtype == torch.bool else (2 if attn_mask.dtype == torch.float16 else 3)
+        strides = (ctypes.c_int64 * 4)(*attn_mask.stride())
+        L.check(L.lib().sage_attn_qk_int8_pv_f16_masked(
+            L.desc(q8, tensor_layout), L.desc(k8, tensor_layout), L.desc(v, tensor_layout), L.SAGE_F16,
+            L.desc(o, tensor_layout), L.dtype_code(dtype), qs.data_ptr(), ks.data_ptr(), attn_mask.data_ptr(), kind, strides,
+            L.ptr(lse2), B, Hq, Hk, M, N, D, L.GRAN_PER_BLOCK, 128, 128, float(sm_scale), 1, L.stream_ptr(q.device)),
+            "sage_attn_qk_int8_pv_f16_masked")
+        o = o[..., :head_dim_og]
+        if return_lse:
+            return o, _finish_lse(lse2, corr if smooth_k else None, sm_scale)
+        return o
 
 
 @torch.compiler.disable

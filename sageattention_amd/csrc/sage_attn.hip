@@ -46,6 +46,12 @@ struct AttnParams {
   const uint16_t* km;
   int q_bf16;
   float sm_scale;
+  // attn_mask of sageattn_qk_int8_pv_fp16_triton (core.py:306-318; kernels attn_qk_int8_per_block.py:33-52):
+  // [B,H,M,N] view with element strides (0 = broadcast); kind 1 = bool (False -> -1e6), 2 = fp16, 3 = bf16 (added to
+  // the base-2 logits, exactly as the reference adds it after its sm_scale*log2e scaling)
+  const uint8_t* mask;
+  int64_t msb, msh, msm, msn;
+  int mask_kind;
 };
 
 __device__ __forceinline__ float swap_max(float x) {
@@ -125,12 +131,13 @@ __device__ __forceinline__ int v_win_swz(int row) {
 // PV_FP8 = false: V fp16 [N][D] row major (bf16 converted on the fly), PV on v_mfma_f32_32x32x16_f16.
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
-template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8>
+template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8, bool HAS_MASK>
 #ifndef SAGE_MINWAVES
 #define SAGE_MINWAVES 2
 #endif
 __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(const AttnParams p) {
   static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
+  static_assert(!HAS_MASK || (!CAUSAL && !PV_FP8 && !V_BF16), "attn_mask: non-causal fp16-PV operator, fp16 V");
   constexpr int T = NWAVES * 64;
   constexpr int QB = NWAVES * 32;
   constexpr int KS = D / 32;          // k-steps of the int8 QK^T MFMA
@@ -431,15 +438,93 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       sc0 = sc1 = qsc * uniform_load1(ksp + j);
     }
   };
-  auto mask_scores = [&](const int j, v16i (&s)[2]) __attribute__((always_inline)) {
+  // which of the lane's 32 keys of tile j may be attended: bit 16*mt+e.  Sequence end, causal diagonal and the
+  // caller's bool attn_mask (False = masked; the reference adds -1e6, which is the same for every row that keeps
+  // at least one key; rows with no allowed key at all are undefined there -- they depend on its tile skipping).
+  // attn_mask exists only on the non-causal fp16-PV operator; bf16 V (register-staged, highest register pressure) is
+  // converted to fp16 by the host for masked calls, as the reference does (core.py:289-290)
+  constexpr bool CAN_MASK = HAS_MASK;  // separate instantiation: the mask bookkeeping must not cost the main variants registers
+  const uint8_t* mrow = nullptr;
+  if constexpr (CAN_MASK)
+    if (p.mask) mrow = p.mask + ((int64_t)b * p.msb + (int64_t)h * p.msh + (int64_t)rowc * p.msm) * (p.mask_kind == 1 ? 1 : 2);
+  struct __attribute__((packed)) u32_unaligned { uint32_t v; };
+  struct __attribute__((packed)) u64_unaligned { uint64_t v; };
+  auto allow_bits = [&](const int j) __attribute__((always_inline)) -> uint32_t {
     const int n0 = j << 6;
+    uint32_t bits = 0;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        s[mt][e] = ((kv >= N_) || (CAUSAL && kv > row)) ? kMaskedI : s[mt][e];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int kv0 = n0 + 32 * mt + 8 * g4 + 4 * hh;  // the lane's keys come in runs of 4: registers 4*g4 .. 4*g4+3
+        uint32_t run = 0;                                 // bit i: key kv0+i allowed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) run |= (((kv0 + i) < N_ && !(CAUSAL && (kv0 + i) > row)) ? 1u : 0u) << i;
+        if constexpr (CAN_MASK) {
+          if (p.mask_kind == 1 && run) {
+            uint32_t mb = 0;
+            if (p.msn == 1 && kv0 + 3 < N_) {  // 4 mask bytes in one (unaligned) dword
+              const uint32_t w = reinterpret_cast<const u32_unaligned*>(mrow + kv0)->v;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) mb |= (((w >> (8 * i)) & 0xffu) ? 1u : 0u) << i;
+            } else {
+#pragma unroll 1
+              for (int i = 0; i < 4; ++i)
+                if (kv0 + i < N_) mb |= (mrow[(int64_t)(kv0 + i) * p.msn] ? 1u : 0u) << i;
+            }
+            run &= mb;
+          }
+        }
+        bits |= run << (16 * mt + 4 * g4);
       }
+    return bits;
+  };
+  auto mask_scores = [&](const uint32_t bits, v16i (&s)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[mt][e] = ((bits >> (16 * mt + e)) & 1u) ? s[mt][e] : kMaskedI;
+  };
+  // additive attn_mask: the score registers are rewritten in place with the fp32 base-2 logits
+  // t = S*scale + mask (masked / out-of-range keys: -1e6 as in the reference, attn_qk_int8_per_block.py:40-43)
+  const bool fmask = CAN_MASK && p.mask_kind >= 2;
+  auto to_float_logits = [&](const int j, const uint32_t bits, v16i (&s)[2], const float sc0, const float sc1)
+      __attribute__((always_inline)) {
+    const int n0 = j << 6;
+    const uint16_t* mrow16 = reinterpret_cast<const uint16_t*>(mrow);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int kv0 = n0 + 32 * mt + 8 * g4 + 4 * hh;
+        uint16_t raw[4] = {0, 0, 0, 0};
+        if (p.msn == 1 && kv0 + 3 < N_) {  // 4 mask values in one (unaligned) 8-byte load
+          const uint64_t w = reinterpret_cast<const u64_unaligned*>(mrow16 + kv0)->v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) raw[i] = (uint16_t)(w >> (16 * i));
+        } else {
+#pragma unroll 1
+          for (int i = 0; i < 4; ++i)
+            if (kv0 + i < N_) raw[i] = mrow16[(int64_t)(kv0 + i) * p.msn];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 4 * g4 + i;
+          const float sc = (e & 2) ? sc1 : sc0;
+          const float t = __builtin_fmaf(__int_as_float(s[mt][e]), sc, -kBiasF * sc);
+          float mv = -1.0e6f;
+          if ((bits >> (16 * mt + e)) & 1u) mv = p.mask_kind == 3 ? bf16_bits_to_f32(raw[i]) : f16_bits_to_f32(raw[i]);
+          s[mt][e] = __float_as_int(t + mv);
+        }
+      }
+  };
+  auto row_max_f = [&](const v16i (&s)[2]) __attribute__((always_inline)) -> float {
+    float mx = __int_as_float(s[0][0]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, __int_as_float(s[mt][e]));
+    return swap_max(mx);
   };
   // row max of the logits of one tile, from the raw integers (scales are positive): v_max3_i32 + 1 cvt/group
   auto row_max = [&](const v16i (&s)[2], const float sc0, const float sc1) __attribute__((always_inline)) -> float {
@@ -474,21 +559,25 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     }
   };
   // p = exp2(t - m) and O^T += V^T . P^T
+  uint32_t bits_cur = 0xffffffffu, bits_nxt = 0xffffffffu;  // allow masks of tiles j / j+1 (generic loop only)
   auto softmax_pv = [&](const int j, const int vbuf, const v16i (&s)[2], const float sc0, const float sc1,
                         auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    const int n0 = j << 6;
     const float c0 = __builtin_fmaf(-kBiasF, sc0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, sc1, kPOff - m_run);
     auto prob = [&](const int mt, const int e) __attribute__((always_inline)) -> float {
       const bool g1 = (e & 2) != 0;
+      float pv;
+      if (MASKED && fmask) {
+        pv = __builtin_amdgcn_exp2f(__int_as_float(s[mt][e]) - m_run + kPOff);  // registers hold fp32 logits
+      } else {
 #ifdef SAGE_ABL_NOEXP
-      float pv = __builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0);
+        pv = __builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0);
 #else
-      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
+        pv = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
 #endif
+      }
       if constexpr (MASKED) {
-        const int kv = n0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        pv = ((kv >= N_) || (CAUSAL && kv > row)) ? 0.f : pv;
+        if (!fmask) pv = ((bits_cur >> (16 * mt + e)) & 1u) ? pv : 0.f;
       }
       return pv;
     };
@@ -562,8 +651,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   int n_plain = wave_tiles;
   if (N_ & 63) n_plain = min(n_plain, N_ >> 6);
   if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
-  const int n_fast = max(0, min(n_plain - 1, wave_tiles - 1));
-  auto needs_mask = [&](const int j) { return ((j << 6) + 64 > N_) || (CAUSAL && ((j << 6) + 63 > q0)); };
+  const int n_fast = (CAN_MASK && p.mask) ? 0 : max(0, min(n_plain - 1, wave_tiles - 1));  // attn_mask: all tiles generic
 
   dma_k(0, 0);
   load_v(0, 0);
@@ -572,12 +660,36 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   dma_wait_all();
   __syncthreads();
 
+  if constexpr (HAS_MASK) {
+    // attn_mask instantiation: plain serial loop (K and V one tile ahead), every tile through the masked body.
+    // A tile in which this wave's 32 rows keep no key is skipped (the reference skips all-False 128x64 tiles,
+    // attn_qk_int8_per_block.py:38-39).
+    v16i s_cur[2];
+    float sc0, sc1;
+    for (int j = 0; j < ntiles; ++j) {
+      const int buf = j & 1;
+      if (j + 1 < ntiles) { dma_k(j + 1, buf ^ 1); load_v(j + 1, buf ^ 1); }
+      bits_cur = allow_bits(j);
+      if (__builtin_amdgcn_ballot_w64(bits_cur != 0) != 0) {
+        tile_scales(j, sc0, sc1);
+        qk(buf, s_cur);
+        float mx;
+        if (fmask) { to_float_logits(j, bits_cur, s_cur, sc0, sc1); mx = row_max_f(s_cur); }
+        else { mask_scores(bits_cur, s_cur); mx = row_max(s_cur, sc0, sc1); }
+        maybe_rescale(mx);
+        softmax_pv(j, buf, s_cur, sc0, sc1, std::true_type{});
+      }
+      dma_wait_all();
+      __syncthreads();
+    }
+  } else {
   v16i s_cur[2], s_nxt[2];
   float sc0, sc1, mx_cur;
   qk(0, s_cur);
   tile_scales(0, sc0, sc1);
-  if (needs_mask(0)) mask_scores(0, s_cur);
-  mx_cur = row_max(s_cur, sc0, sc1);
+  bits_cur = allow_bits(0);
+  if (fmask) { to_float_logits(0, bits_cur, s_cur, sc0, sc1); mx_cur = row_max_f(s_cur); }
+  else { mask_scores(bits_cur, s_cur); mx_cur = row_max(s_cur, sc0, sc1); }
 
   // fast loop, unrolled by two so that S(j) / S(j+1) swap roles without register copies
   auto fast_iter = [&](auto par_tag, const int j, v16i (&sa)[2], v16i (&sb)[2], float& a0, float& a1, float& b0,
@@ -606,6 +718,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
     fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
+  if (j > 0 && j < wave_tiles) bits_cur = allow_bits(j);  // first generic tile after the fast loop (its max is already in)
   for (; j < wave_tiles; ++j) {
     maybe_rescale(mx_cur);
     if (j + 2 < ntiles) dma_k(j + 2, j & 1);
@@ -614,10 +727,12 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     if (has_next) {
       tile_scales(j + 1, nsc0, nsc1);
       qk((j + 1) & 1, s_nxt);
-      if (needs_mask(j + 1)) mask_scores(j + 1, s_nxt);
+      bits_nxt = allow_bits(j + 1);
+      if (fmask) to_float_logits(j + 1, bits_nxt, s_nxt, nsc0, nsc1); else mask_scores(bits_nxt, s_nxt);
     }
     softmax_pv(j, j & 1, s_cur, sc0, sc1, std::true_type{});
-    if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
+    if (has_next) mx_cur = fmask ? row_max_f(s_nxt) : row_max(s_nxt, nsc0, nsc1);
+    bits_cur = bits_nxt;
     if (j + 1 < ntiles) store_v((j + 1) & 1);
     dma_wait_all();
     __syncthreads();
@@ -629,6 +744,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     if (j + 1 < ntiles) { load_v(j + 1, (j + 1) & 1); store_v((j + 1) & 1); }
     dma_wait_all();
     __syncthreads();
+  }
+
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
@@ -675,11 +792,27 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
 
 template <int D, int NWAVES, bool PV_FP8>
 static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf16, hipStream_t st) {
+  if constexpr (!PV_FP8) {
+    if (p.mask) {  // attn_mask variant (non-causal, fp16 V: checked by run_attn)
+      const size_t smem_m = 2 * 64 * D + 2 * 64 * D * 2;
+      const dim3 grid_m(p.nqb * p.Hq * p.B), block_m(NWAVES * 64);
+      if (kthread) {
+        auto kern = attn_i8_kernel<D, NWAVES, false, true, false, false, true>;
+        if (smem_m > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
+        hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);
+      } else {
+        auto kern = attn_i8_kernel<D, NWAVES, false, false, false, false, true>;
+        if (smem_m > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
+        hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);
+      }
+      return launch_status();
+    }
+  }
   const size_t smem = 2 * 64 * D + 2 * (PV_FP8 ? 64 * D : 64 * D * 2);
   const dim3 grid(p.nqb * p.Hq * p.B), block(NWAVES * 64);
 #define SAGE_LAUNCH(C, K, V)                                                                                       \
   do {                                                                                                             \
-    auto kern = attn_i8_kernel<D, NWAVES, C, K, V, PV_FP8>;                                                        \
+    auto kern = attn_i8_kernel<D, NWAVES, C, K, V, PV_FP8, false>;                                                      \
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                            \
   } while (0)
@@ -708,7 +841,9 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
                     const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale, const float* v_scale,
                     const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal, int qk_gran,
                     int blkq, int warpq, float sm_scale, int logit_mult_is_one, hipStream_t st,
-                    const int* cu_q = nullptr, const int* cu_k = nullptr, int q_dtype = -1, const void* km = nullptr) {
+                    const int* cu_q = nullptr, const int* cu_k = nullptr, int q_dtype = -1, const void* km = nullptr,
+                    const void* mask = nullptr, int mask_kind = 0, const int64_t* mask_strides = nullptr) {
+  if (mask && (mask_kind < 1 || mask_kind > 3 || !mask_strides || is_causal || pv_fp8 || cu_q || v_dtype != SAGE_F16)) return SAGE_ERR_INVALID_ARGUMENT;
   const bool fusedq = q_dtype >= 0;  // q8 is then the fp16/bf16 query tensor
   if ((cu_q == nullptr) != (cu_k == nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
   if (fusedq) {
@@ -748,6 +883,8 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.logit_mult = logit_mult_is_one ? 1.0f : sm_scale * kLog2e;
   p.out_bf16 = o_dtype == SAGE_BF16;
   p.cu_q = cu_q; p.cu_k = cu_k;
+  p.mask = (const uint8_t*)mask; p.mask_kind = mask ? mask_kind : 0;
+  p.msb = mask ? mask_strides[0] : 0; p.msh = mask ? mask_strides[1] : 0; p.msm = mask ? mask_strides[2] : 0; p.msn = mask ? mask_strides[3] : 0;
   p.q_f16 = fusedq ? (const uint16_t*)q8->data : nullptr;
   p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
@@ -819,4 +956,15 @@ extern "C" int sage_attn_fusedq_pv_f8(const sage_tensor* q, int q_dtype, const s
   if (q_dtype != SAGE_F16 && q_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
   return run_attn(q, k8, v_fp8, true, SAGE_F16, o, o_dtype, nullptr, k_scale, v_scale, v_mean, lse, B, Hq, Hk, M, N, D,
                   is_causal, qk_gran, 128, warpq, sm_scale, 0, (hipStream_t)stream, nullptr, nullptr, q_dtype, km);
+}
+
+extern "C" int sage_attn_qk_int8_pv_f16_masked(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, int v_dtype,
+                                               const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                               const void* attn_mask, int mask_kind, const int64_t* mask_strides, float* lse,
+                                               int B, int Hq, int Hk, int M, int N, int D, int qk_gran, int blkq, int warpq,
+                                               float sm_scale, int logit_mult_is_one, sage_stream_t stream) {
+  if (!attn_mask) return SAGE_ERR_INVALID_ARGUMENT;
+  return run_attn(q8, k8, v, false, v_dtype, o, o_dtype, q_scale, k_scale, nullptr, nullptr, lse, B, Hq, Hk, M, N, D, 0, qk_gran,
+                  blkq, warpq, sm_scale, logit_mult_is_one, (hipStream_t)stream, nullptr, nullptr, -1, nullptr, attn_mask,
+                  mask_kind, mask_strides);
 }

@@ -1,0 +1,92 @@
+"""attn_mask of sageattn_qk_int8_pv_fp16_triton (reference core.py:249-251,302-318).  Golden vectors:
+tests/golden/masked/masked_d64.npz from the reference's per-block Triton kernel with a bool and an additive mask."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, calc_diff
+
+
+def _load():
+    z = np.load(os.path.join(GOLDEN_DIR, "masked", "masked_d64.npz"), allow_pickle=False)
+    f16 = lambda a: torch.from_numpy(a.view(np.int16).copy()).view(torch.float16)
+    g = {k: f16(z[k]) for k in ("q", "k", "v", "km", "mask_float", "o_bool", "o_float")}
+    g.update({k: torch.from_numpy(z[k].copy()) for k in ("q8", "k8", "qs", "ks", "mask_bool", "lse2_bool", "lse2_float")})
+    return g
+
+
+def _rows_with_keys(mask_bool):
+    return mask_bool.any(dim=-1)  # [M]: rows that keep at least one key (others are undefined in the reference)
+
+
+def test_masked_oracle_vs_reference():
+    from oracle import sage_oracle as O
+    g = _load()
+    M, N = g["q8"].shape[2], g["k8"].shape[2]
+    qrows, kcols = O.expand_q_scale(g["qs"], M, "per_block"), O.expand_k_scale(g["ks"], N, "per_block")
+    ok = _rows_with_keys(g["mask_bool"])
+    for key, mask in (("bool", g["mask_bool"].view(1, 1, M, N).expand(1, 2, M, N)),
+                      ("float", g["mask_float"].view(1, 1, M, N).expand(1, 2, M, N))):
+        o, lse2 = O.attn_tile_loop(g["q8"], g["k8"], g["v"], qrows, kcols, logit_mult=1.0, flavor="triton", attn_mask=mask)
+        ref, rl = g[f"o_{key}"].float(), g[f"lse2_{key}"]
+        sel = ok if key == "bool" else torch.ones_like(ok)
+        assert ((o.float() - ref).abs() <= 2 * 2.0 ** -10 * ref.abs().clamp(min=0.25))[:, :, sel].all()
+        assert (lse2 - rl)[:, :, sel].abs().max() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["bool", "float"])
+def test_masked_hip_vs_reference(kind):
+    """The HIP kernel fed the int8 tensors and scales of the fixture, against the reference output (|do| <= 4e-3, as
+    for the unmasked kernel) and its base-2 LSE; fully masked rows excluded (undefined in the reference)."""
+    from sageattention_amd import _lib as L
+    import ctypes
+    g = _load()
+    M, N, D = g["q8"].shape[2], g["k8"].shape[2], 64
+    mask = (g["mask_bool"] if kind == "bool" else g["mask_float"][0]).cuda().view(1, 1, M, N).expand(1, 2, M, N)
+    o = torch.empty(1, 2, M, D, dtype=torch.float16, device="cuda")
+    lse = torch.empty(1, 2, M, dtype=torch.float32, device="cuda")
+    q8, k8, v = g["q8"].cuda(), g["k8"].cuda(), g["v"].cuda()
+    qs, ks = g["qs"].cuda(), g["ks"].cuda()
+    st = (ctypes.c_int64 * 4)(*mask.stride())
+    for nw in (8, 4):
+        L.lib().sage_set_tuning(0, nw)
+        L.check(L.lib().sage_attn_qk_int8_pv_f16_masked(
+            L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(v, "HND"), 0, L.desc(o, "HND"), 0, qs.data_ptr(), ks.data_ptr(),
+            mask.data_ptr(), 1 if kind == "bool" else 2, st, lse.data_ptr(), 1, 2, 2, M, N, D, 1, 128, 128, D ** -0.5, 1,
+            torch.cuda.current_stream().cuda_stream), "masked")
+        torch.cuda.synchronize()
+        L.lib().sage_set_tuning(0, 0)
+        sel = _rows_with_keys(g["mask_bool"]) if kind == "bool" else torch.ones(M, dtype=torch.bool)
+        ref, rl = g[f"o_{kind}"].float(), g[f"lse2_{kind}"]
+        assert (o.cpu().float() - ref)[:, :, sel].abs().max() < 4e-3
+        assert calc_diff(o.cpu().float()[:, :, sel], ref[:, :, sel]) < 1e-5
+        assert (lse.cpu() - rl)[:, :, sel].abs().max() < 5e-4
+
+
+@pytest.mark.gpu
+def test_masked_api_end_to_end():
+    """Public entry point with broadcastable masks (bool [M,N], additive [B,1,1,N] padding mask), NHD layout, bf16, GQA."""
+    import sageattention_amd as sa
+    from oracle import sage_oracle as O
+    torch.manual_seed(11)
+    B, Hq, Hk, M, N, D = 2, 4, 2, 150, 260, 128
+    q = torch.randn(B, M, Hq, D).bfloat16(); k = torch.randn(B, N, Hk, D).bfloat16(); v = torch.randn(B, N, Hk, D).bfloat16()
+    mb = torch.rand(M, N) > 0.4
+    mb[:, 0] = True
+    pad = torch.zeros(B, 1, 1, N); pad[0, ..., 200:] = -1e4; pad = pad.bfloat16()
+    for mask in (mb, pad):
+        o = sa.sageattn_qk_int8_pv_fp16_triton(q.cuda(), k.cuda(), v.cuda(), tensor_layout="NHD", attn_mask=mask.cuda())
+        torch.cuda.synchronize()
+        full = mask.expand(B, Hq, M, N)
+        s = torch.einsum("bmhd,bnhd->bhmn", q.float(), k.float().repeat_interleave(2, dim=2)) * D ** -0.5
+        s = s + (torch.where(full, 0.0, float("-inf")) if full.dtype == torch.bool else full.float() * 0.6931471805599453)
+        ref = torch.einsum("bhmn,bnhd->bmhd", torch.softmax(s, -1), v.float().repeat_interleave(2, dim=2))
+        assert o.shape == q.shape and o.dtype == torch.bfloat16
+        assert (o.cpu().float() - ref).abs().max() < 0.08
+    with pytest.raises(AssertionError):
+        sa.sageattn_qk_int8_pv_fp16_triton(q.cuda(), k.cuda(), v.cuda(), tensor_layout="NHD", attn_mask=mb.cuda(), is_causal=True)
+    with pytest.raises(AssertionError):
+        sa.sageattn_qk_int8_pv_fp16_triton(q.cuda(), k.cuda(), v.cuda(), tensor_layout="NHD", attn_mask=torch.ones(3, 7, dtype=torch.bool).cuda())
