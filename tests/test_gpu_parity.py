@@ -346,3 +346,47 @@ def test_fused_q_quantizer_is_bit_identical(sa, golden, gran, pv):
     torch.cuda.synchronize()
     assert torch.equal(o1, o0), (o1.float() - o0.float()).abs().max()
     assert (l1 - l0).abs().max() < 1e-5 * max(1.0, float(l0.abs().max()))
+
+
+def test_randomized_sweep_vs_oracle(sa):
+    """40 seeded random configurations (layout, dtype, GQA ratio, M != N, head_dim incl. padded ones, granularity,
+    causal, PV precision, smoothing flags, workgroup size) against the oracle; tolerances of the golden tests."""
+    import random
+    from oracle import sage_oracle as O
+    from sageattention_amd import _lib as L
+    rng = random.Random(20250101)
+    for it in range(40):
+        layout = rng.choice(["HND", "NHD"])
+        dt = rng.choice([torch.float16, torch.bfloat16])
+        Hk = rng.choice([1, 2, 3])
+        Hq = Hk * rng.choice([1, 2, 4])
+        D = rng.choice([64, 128, 64, 128, 40, 96])
+        causal = rng.random() < 0.4
+        M = rng.randint(1, 400)
+        N = M if (causal and rng.random() < 0.7) else rng.randint(1, 600)
+        B = rng.choice([1, 2])
+        pv = rng.choice(["fp16", "fp8"])
+        gran = rng.choice(["per_warp", "per_thread"])
+        smooth_k = rng.random() < 0.8
+        nw = rng.choice([0, 4, 8])
+        g = torch.Generator().manual_seed(it)
+        mk = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
+        q = torch.randn(mk(Hq, M), generator=g).to(dt)
+        k = (torch.randn(mk(Hk, N), generator=g) + rng.choice([0.0, 2.0]) * torch.randn(mk(Hk, 1), generator=g)).to(dt)
+        v = torch.randn(mk(Hk, N), generator=g).to(dt)
+        fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+        L.lib().sage_set_tuning(0, nw)
+        try:
+            o, lse = fn(q.cuda(), k.cuda(), v.cuda(), tensor_layout=layout, is_causal=causal, qk_quant_gran=gran,
+                        smooth_k=smooth_k, return_lse=True, pv_accum_dtype="fp32")
+            torch.cuda.synchronize()
+        finally:
+            L.lib().sage_set_tuning(0, 0)
+        oo, ol = O.sageattn_oracle(q, k, v, tensor_layout=layout, is_causal=causal, qk_quant_gran=gran, pv=pv,
+                                   smooth_k=smooth_k, return_lse=True)
+        cfg = (it, layout, dt, Hq, Hk, D, causal, M, N, B, pv, gran, smooth_k, nw)
+        assert o.shape == q.shape and torch.isfinite(o).all(), cfg
+        tol = {("fp16", torch.float16): 2e-3, ("fp16", torch.bfloat16): 1.6e-2, ("fp8", torch.float16): 0.06,
+               ("fp8", torch.bfloat16): 0.07}[(pv, dt)]
+        assert (o.cpu().float() - oo.float()).abs().max() < tol, cfg
+        assert (lse.cpu() - ol).abs().max() < 3e-3, cfg
