@@ -54,9 +54,20 @@ struct AttnParams {
   int mask_kind;
 };
 
+// v_max_f32 on values that are never signalling NaNs: fmaxf() makes hipcc canonicalise both operands first
+// (v_max_f32 x, x, x), two extra instructions on a kernel bound by the vector issue port
+__device__ __forceinline__ float max_raw(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a > b ? a : b;
+#endif
+}
 __device__ __forceinline__ float swap_max(float x) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float swap_sum(float x) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -411,6 +422,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   v16i bias;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = kBiasI;
+  // keep the 16 bias registers resident: as a known constant the compiler re-materialises them with 8 v_mov_b64 per
+  // tile, and the kernel is bound by the vector issue port (every VALU instruction costs 4 cycles of it).  Not in the
+  // attn_mask instantiation, which has no registers to spare.
+  if constexpr (!HAS_MASK) asm volatile("" : "+v"(bias));
 
   // S^T = K . Q^T for one tile (2 x 32 keys x 32 query rows) out of LDS buffer `kbuf`
   auto qk = [&](const int kbuf, v16i (&s)[2]) __attribute__((always_inline)) {
@@ -427,16 +442,24 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       }
   };
   // dequantisation scales of tile j: …sm80.cu:131, 4 per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
-  auto tile_scales = [&](const int j, float& sc0, float& sc1) __attribute__((always_inline)) {
+  // wave-uniform address: the scales of a tile come through the scalar cache (s_load_dwordx4, lgkmcnt), not through
+  // vmcnt where they would queue behind the tile DMA.  The lane-half select is an fma with a zeroed partner
+  // (x*q + z*0 is exactly x*q) instead of two v_mov + v_cndmask per scale: SGPR operands feed the VALU directly.
+  const float qsc_lo = hh ? 0.f : qsc, qsc_hi = hh ? qsc : 0.f;
+  auto load_kscales = [&](const int j) __attribute__((always_inline)) -> float4 {
+    if constexpr (KTHREAD) return uniform_load4(ksp + j * 4);
+    else return make_float4(uniform_load1(ksp + j), 0.f, 0.f, 0.f);
+  };
+  auto scales_from = [&](const float4 kk, float& sc0, float& sc1) __attribute__((always_inline)) {
     if constexpr (KTHREAD) {
-      // wave-uniform address: the 4 scales of the tile come through the scalar cache (s_load_dwordx4, lgkmcnt),
-      // not through vmcnt where they would queue behind the tile DMA
-      const float4 kk = uniform_load4(ksp + j * 4);
-      sc0 = qsc * (hh ? kk.z : kk.x);
-      sc1 = qsc * (hh ? kk.w : kk.y);
+      sc0 = __builtin_fmaf(kk.z, qsc_hi, kk.x * qsc_lo);
+      sc1 = __builtin_fmaf(kk.w, qsc_hi, kk.y * qsc_lo);
     } else {
-      sc0 = sc1 = qsc * uniform_load1(ksp + j);
+      sc0 = sc1 = qsc * kk.x;
     }
+  };
+  auto tile_scales = [&](const int j, float& sc0, float& sc1) __attribute__((always_inline)) {
+    scales_from(load_kscales(j), sc0, sc1);
   };
   // which of the lane's 32 keys of tile j may be attended: bit 16*mt+e.  Sequence end, causal diagonal and the
   // caller's bool attn_mask (False = masked; the reference adds -1e6, which is the same for every row that keeps
@@ -535,9 +558,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       for (int e = 0; e < 16; ++e) {
         if (e & 2) mxb = max(mxb, s[mt][e]); else mxa = max(mxa, s[mt][e]);
       }
+    // the biased integers are the floats 12582912 + S: one v_sub_f32 recovers S exactly (no v_cvt_f32_i32)
     float mx;
-    if constexpr (KTHREAD) mx = fmaxf((float)(mxa - kBiasI) * sc0, (float)(mxb - kBiasI) * sc1);
-    else mx = (float)(max(mxa, mxb) - kBiasI) * sc0;
+    if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * sc0, (__int_as_float(mxb) - kBiasF) * sc1);
+    else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * sc0;
     return swap_max(mx);
   };
   // lazy rescale (attn_utils.cuh:354-458 rescales every tile; here only when some row's max grew by more than
@@ -546,11 +570,13 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // max); the lazy threshold is taken out of that headroom so p <= 2^(kLazyThr + kPOff) = 448 still holds.
   constexpr float kLazyThr = PV_FP8 ? 3.0f : 6.0f;
   constexpr float kPOff = PV_FP8 ? 8.807f - 3.0f : 0.f;
+  float m_thr = m_run + kLazyThr;  // kept in a register: the comparison runs every tile, the update almost never
   auto maybe_rescale = [&](const float mx) __attribute__((always_inline)) {
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m_run + kLazyThr) != 0, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m_thr) != 0, 0)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
+      m_thr = m_new + kLazyThr;
       l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
@@ -692,6 +718,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   else { mask_scores(bits_cur, s_cur); mx_cur = row_max(s_cur, sc0, sc1); }
 
   // fast loop, unrolled by two so that S(j) / S(j+1) swap roles without register copies
+  float4 kk_nxt = load_kscales(min(1, ntiles - 1));
   auto fast_iter = [&](auto par_tag, const int j, v16i (&sa)[2], v16i (&sb)[2], float& a0, float& a1, float& b0,
                        float& b1) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;  // j & 1, static so every LDS offset is an immediate
@@ -700,7 +727,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     if (j + 2 < ntiles) dma_k(j + 2, PAR);
     load_v(j + 1, PAR ^ 1);
 #endif
-    tile_scales(j + 1, b0, b1);
+    // scales of tile j+1 were fetched during the previous iteration; fetch those of tile j+2 now (a scalar load
+    // issued right in front of its use would expose the scalar-cache latency behind the workgroup barrier)
+    scales_from(kk_nxt, b0, b1);
+    kk_nxt = load_kscales(min(j + 2, ntiles - 1));
     qk(PAR ^ 1, sb);
     softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
     mx_cur = row_max(sb, b0, b1);
