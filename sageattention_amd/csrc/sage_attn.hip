@@ -679,6 +679,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
   const int n_fast = (CAN_MASK && p.mask) ? 0 : max(0, min(n_plain - 1, wave_tiles - 1));  // attn_mask: all tiles generic
 
+#ifdef SAGE_EXP_PRIO
+  // experiment: static priority for the second-dispatched half of the workgroup (MI355X guide, two waves per SIMD item 4)
+  if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(SAGE_EXP_PRIO);
+#endif
   dma_k(0, 0);
   load_v(0, 0);
   store_v(0);
@@ -731,9 +735,120 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     // issued right in front of its use would expose the scalar-cache latency behind the workgroup barrier)
     scales_from(kk_nxt, b0, b1);
     kk_nxt = load_kscales(min(j + 2, ntiles - 1));
-    qk(PAR ^ 1, sb);
-    softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
-    mx_cur = row_max(sb, b0, b1);
+#ifdef SAGE_SCHED_COMPILER
+    constexpr bool HAND_PLACED = false;
+#else
+    constexpr bool HAND_PLACED = !PV_FP8;
+#endif
+    if constexpr (!HAND_PLACED) {
+      qk(PAR ^ 1, sb);
+      softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
+      mx_cur = row_max(sb, b0, b1);
+    } else {
+      // Hand-placed instruction stream (fp16 PV).  The wave issues in order and an MFMA that finds the matrix pipe
+      // busy blocks the VALU instructions behind it, so what counts is what sits BETWEEN consecutive MFMAs: about
+      // 24 cycles of vector issue hide beside a 32-cycle MFMA (tools/issue_cost.hip).  Left to itself hipcc emits the
+      // S(j+1) MFMAs as one burst, P.V MFMAs with nothing but LDS reads between them, and the row sums / row max as a
+      // VALU-only tail.  Here the tile is cut into quarters of 16 keys: P of quarter q+1 is computed beside the P.V
+      // MFMAs of quarter q, the S(j+1) MFMAs are spread between them, V^T fragments are read one quarter ahead, and
+      // the row max of S(j+1) runs beside the last quarter's MFMAs.  sched_barrier(0) pins each group.
+      constexpr int NS = 2 * KS, SPR = NS / 4;  // S MFMAs per tile / per region
+      constexpr int PPG = 4 / DT;               // P pairs computed beside one P.V MFMA
+      const char* const kb = k_lds + (PAR ^ 1) * KBYTES;
+      const char* const vb = v_lds + PAR * VBYTES;
+      const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
+      auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
+        return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
+      };
+      auto v_frag = [&](const int q, const int dt) __attribute__((always_inline)) -> v8h {
+        const char* base = vb + 16 * q * (2 * D) + v_rd[dt];
+        const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
+        const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
+        v8h a;
+        a.s0123 = __builtin_bit_cast(v4h, lo);
+        a.s4567 = __builtin_bit_cast(v4h, hi);
+        return a;
+      };
+      auto s_step = [&](const int i, const v4i a) __attribute__((always_inline)) {
+        const int mt = i / KS, ks = i % KS;
+        sb[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : sb[mt], 0, 0, 0);
+      };
+      float pp[8];  // unrounded p of the quarter in flight (row-sum operands)
+      auto p_pair = [&](const int q, const int pr, v8h& pf) __attribute__((always_inline)) {
+        const int mt = q >> 1, e = 8 * (q & 1) + 2 * pr;
+        const bool g1 = (e & 2) != 0;
+        const float sc = g1 ? a1 : a0, cc = g1 ? c1 : c0;
+        v2f two = {__builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(sa[mt][e]), sc, cc)),
+                   __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(sa[mt][e + 1]), sc, cc))};
+        const v2h ph = __builtin_convertvector(two, v2h);  // v_cvt_pk_f16_f32, RNE
+        pf[2 * pr] = ph[0];
+        pf[2 * pr + 1] = ph[1];
+        pp[2 * pr] = two[0];
+        pp[2 * pr + 1] = two[1];
+      };
+      auto p_sum = [&](const int pr) __attribute__((always_inline)) { l_run += pp[2 * pr]; l_run += pp[2 * pr + 1]; };
+#define SAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+      v4i kf = k_frag(0);
+      v8h vf[DT], vn[DT], pf, pn;
+      // region 0: P(quarter 0) beside the first S MFMAs; V^T fragments of quarter 0
+#pragma unroll
+      for (int g = 0; g < SPR; ++g) {
+        s_step(g, kf);
+        kf = k_frag(g + 1);
+#pragma unroll
+        for (int dt = g * (DT / SPR); dt < (g + 1) * (DT / SPR); ++dt) vf[dt] = v_frag(0, dt);
+#pragma unroll
+        for (int pr = g * (4 / SPR); pr < (g + 1) * (4 / SPR); ++pr) {
+          if (pr > 0) p_sum(pr - 1);
+          p_pair(0, pr, pf);
+        }
+        SAGE_FENCE();
+      }
+      // regions 1..3: P.V of quarter q-1 | P(quarter q) | S MFMAs | V^T fragments of quarter q
+      int si = SPR;
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt], pf, acc_o[dt], 0, 0, 0);
+          vn[dt] = v_frag(q, dt);
+#pragma unroll
+          for (int pr = dt * PPG; pr < (dt + 1) * PPG; ++pr) {
+            p_sum(pr == 0 ? 3 : pr - 1);  // the pair computed one step earlier (pair 3 of the previous quarter first)
+            p_pair(q, pr, pn);
+          }
+          SAGE_FENCE();
+          if ((dt + 1) % (DT / SPR) == 0) {
+            s_step(si, kf);
+            if (si + 1 < NS) kf = k_frag(si + 1);
+            ++si;
+            SAGE_FENCE();
+          }
+        }
+        pf = pn;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vf[dt] = vn[dt];
+      }
+      // tail: P.V of quarter 3 beside the row max of S(j+1)
+      p_sum(3);
+      int mxa = sb[0][0], mxb = sb[0][2];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt], pf, acc_o[dt], 0, 0, 0);
+#pragma unroll
+        for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
+          const int mt = idx >> 4, e = idx & 15;
+          if (e & 2) mxb = max(mxb, sb[mt][e]); else mxa = max(mxa, sb[mt][e]);
+        }
+        asm volatile("" : "+v"(mxa), "+v"(mxb));  // keeps this part of the max chain here (integer max re-associates)
+        SAGE_FENCE();
+      }
+#undef SAGE_FENCE
+      float mx;
+      if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * b0, (__int_as_float(mxb) - kBiasF) * b1);
+      else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
+      mx_cur = swap_max(mx);
+    }
 #ifndef SAGE_ABL_NOSTAGE
     store_v(PAR ^ 1);
     dma_wait_all();
