@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--pv", default=None, choices=["fp16", "fp8"], help="override the PV precision of the workload")
     ap.add_argument("--causal", default=None, type=int, choices=[0, 1], help="override the workload's causal flag")
     ap.add_argument("--schedule", default="direct", choices=["direct", "ring"], help="N>1: KV exchange schedule")
+    ap.add_argument("--causal-layout", default="zigzag", choices=["zigzag", "contiguous"],
+                    help="N>1 causal: zigzag half-blocks (balanced, default) or contiguous shards")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to "
                     "rehearse the multi-process path with several ranks on ONE GPU")
     ap.add_argument("--seq", type=int, default=None, help="override the workload's sequence length (rehearsals)")
@@ -135,8 +137,9 @@ def main():
         v = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
 
         def step():
-            return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant, schedule=args.schedule)
-        parallelism = f"seq-parallel{world}-{args.schedule}"
+            return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant, schedule=args.schedule,
+                                      causal_layout=args.causal_layout)
+        parallelism = f"seq-parallel{world}-{args.schedule}" + (f"-{args.causal_layout}" if causal else "")
     else:
         q = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
         k = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)

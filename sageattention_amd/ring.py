@@ -14,6 +14,14 @@ Causal: shards are contiguous in the sequence, so a shard from a later rank is s
 causal, earlier shards are full attention.  Per step and rank the ring moves Hk*n*D bytes of K + 2*Hk*n*D (fp16 V)
 or Hk*n*D (fp8 V) over one xGMI link.
 
+Causal load balance ("zigzag"): with contiguous shards rank 0 computes one block and rank P-1 computes P.
+``causal_layout="zigzag"`` cuts the sequence into 2P chunks and gives rank r the chunks r and 2P-1-r (its local rows
+are their concatenation; ``zigzag_split`` / ``zigzag_merge`` convert).  Chunk a attends chunk b fully when b < a, on
+the diagonal when b == a and not at all when b > a, so against the shard of rank s a rank computes
+    s < r:  (lo,lo) full + (hi,lo) full      s > r:  (hi, lo+hi) full      s == r:  (lo,lo) diag + (hi,lo) full + (hi,hi) diag
+-- two half-block products per step on EVERY rank.  Shards are quantized once, whole; half-blocks are row slices
+of the quantized tensors and of their scale vectors (the chunk length must be a multiple of 128 rows).
+
 Two exchange schedules, same arithmetic (results are bit-identical):
   "ring"   P-1 rotation steps, each overlapped with one block of compute; one xGMI link per direction is busy.
   "direct" the 8 GPUs of an MI355X node are fully connected by xGMI (7 links per GPU), so every rank posts its shard to
@@ -32,7 +40,23 @@ from . import _lib as L
 from . import _qattn
 from .quant import _quant, k_mean, per_channel_fp8
 
-__all__ = ["ring_sageattn", "HipRingBackend"]
+__all__ = ["ring_sageattn", "HipRingBackend", "zigzag_split", "zigzag_merge"]
+
+
+def zigzag_split(x: torch.Tensor, world: int, rank: int, dim: int = 2) -> torch.Tensor:
+    """Rows of rank ``rank`` under the zigzag layout: chunks ``rank`` and ``2*world-1-rank`` of 2*world equal chunks."""
+    chunks = x.chunk(2 * world, dim=dim)
+    return torch.cat([chunks[rank], chunks[2 * world - 1 - rank]], dim=dim)
+
+
+def zigzag_merge(parts, dim: int = 2) -> torch.Tensor:
+    """Inverse of zigzag_split over the list of per-rank tensors (rank order)."""
+    world = len(parts)
+    chunks = [None] * (2 * world)
+    for r, t in enumerate(parts):
+        lo, hi = t.chunk(2, dim=dim)
+        chunks[r], chunks[2 * world - 1 - r] = lo, hi
+    return torch.cat(chunks, dim=dim)
 
 
 class HipRingBackend:
@@ -64,6 +88,23 @@ class HipRingBackend:
             parts["v"] = v8
             parts["vs"] = vsc
         return parts
+
+    # -- row ranges of the quantized tensors (zigzag half-blocks); r0 % 128 == 0
+    def slice_q(self, qstate, r0, r1):
+        per = 32 if self.gran == "per_thread" else 4  # q scales per 128 rows (BLKQ 128, WARPQ 32)
+        return {"q": qstate["q"][:, :, r0:r1], "q8": qstate["q8"][:, :, r0:r1],
+                "qs": qstate["qs"][:, :, r0 // 128 * per:-(-r1 // 128) * per].contiguous(), "sm_scale": qstate["sm_scale"]}
+
+    def slice_kv(self, kv, r0, r1):
+        per = 4 if self.gran == "per_thread" else 1   # k scales per 64 rows
+        out = {"k8": kv["k8"][:, :, r0:r1], "ks": kv["ks"][:, :, r0 // 64 * per:-(-r1 // 64) * per].contiguous(),
+               "km": kv["km"]}
+        if self.pv == "fp16":
+            out["v"] = kv["v"][:, :, r0:r1]
+        else:  # V^T [B,Hk,D,N_pad]: tokens are the last axis, permuted only inside groups of 64
+            out["v"] = kv["v"][..., r0:-(-r1 // 64) * 64]
+            out["vs"] = kv["vs"]
+        return out
 
     def block_attn(self, qstate, kv, causal: bool):
         """(o_blk [B,H,M,D] in q's dtype, lse [B,H,M] natural log of the true logits) for one KV shard."""
@@ -126,15 +167,22 @@ def _views_like(buf, views):
 def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
                   sm_scale: Optional[float] = None, group: Optional[dist.ProcessGroup] = None, pv: str = "fp16",
                   qk_quant_gran: str = "per_thread", return_lse: bool = False, backend: Any = None,
-                  schedule: str = "direct", **kwargs: Any):
-    """SageAttention over a sequence sharded across the ranks of ``group`` (rank r holds rows [r*n, (r+1)*n) of q, k, v;
-    equal shard lengths).  Same tensor conventions as ``sageattn``; returns this rank's output rows (and their LSE)."""
+                  schedule: str = "direct", causal_layout: str = "contiguous", **kwargs: Any):
+    """SageAttention over a sequence sharded across the ranks of ``group``.  Equal shard lengths; rank r holds rows
+    [r*n, (r+1)*n) of q, k, v (``causal_layout="contiguous"``) or the zigzag rows ``zigzag_split(x, P, r)``
+    (``"zigzag"``, balances causal work; chunk length n/2 must be a multiple of 128).  Same tensor conventions as
+    ``sageattn``; returns this rank's output rows (and their LSE) in the same local order."""
     if tensor_layout == "NHD":
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     elif tensor_layout != "HND":
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
     if schedule not in ("ring", "direct"):
         raise ValueError(f"Unknown schedule: {schedule}")
+    if causal_layout not in ("contiguous", "zigzag"):
+        raise ValueError(f"Unknown causal_layout: {causal_layout}")
+    zigzag = is_causal and causal_layout == "zigzag"
+    if zigzag and (q.size(2) % 256 or k.size(2) != q.size(2)):
+        raise ValueError("zigzag layout needs equal q/kv shard lengths that are a multiple of 256 rows")
     D = q.size(-1)
     if D not in (64, 128):
         raise ValueError(f"ring_sageattn supports head_dim 64 or 128, got {D}")
@@ -151,12 +199,34 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
     cur_buf, cur = _pack(be.prepare_kv(k, v))
     state = be.new_state(q)
 
+    n_loc = q.size(2)
+    half = n_loc // 2
+    if zigzag:  # separate (contiguous) accumulators for the two half-blocks of query rows
+        q_part = {"lo": be.slice_q(qstate, 0, half), "hi": be.slice_q(qstate, half, n_loc)}
+        zstate = {"lo": be.new_state(q[:, :, :half]), "hi": be.new_state(q[:, :, half:])}
+        kv_rng = {"lo": (0, half), "hi": (half, n_loc), "all": (0, n_loc)}
+
+    def skips(src, dst):  # rank dst never touches the shard of rank src
+        return is_causal and not zigzag and src > dst
+
     def consume(views, src):
         nonlocal state
-        if is_causal and src > rank:
+        if skips(src, rank):
             return
-        o_blk, lse_blk = be.block_attn(qstate, views, is_causal and src == rank)
-        state = be.merge(state, o_blk, lse_blk)
+        if not zigzag:
+            o_blk, lse_blk = be.block_attn(qstate, views, is_causal and src == rank)
+            state = be.merge(state, o_blk, lse_blk)
+            return
+        if src < rank:
+            pairs = (("lo", "lo", False), ("hi", "lo", False))
+        elif src > rank:
+            pairs = (("hi", "all", False),)
+        else:
+            pairs = (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True))
+        for qa, kb, diag in pairs:
+            kv = views if kb == "all" else be.slice_kv(views, *kv_rng[kb])
+            o_blk, lse_blk = be.block_attn(q_part[qa], kv, diag)
+            zstate[qa] = be.merge(zstate[qa], o_blk, lse_blk)
 
     if schedule == "ring" or world == 1:
         nxt_buf = torch.empty_like(cur_buf) if world > 1 else None
@@ -178,8 +248,8 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
         # direct exchange over the fully connected xGMI fabric: one send + one receive per peer, all posted at once
         order = [(rank - s) % world for s in range(1, world)]  # same consumption order as the ring
         rbufs = {src: torch.empty_like(cur_buf) for src in order}
-        need = [src for src in order if not (is_causal and src > rank)]          # shards this rank will use
-        wanted_by = [dst for dst in order if not (is_causal and rank > dst)]      # ranks that will use OUR shard
+        need = [src for src in order if not skips(src, rank)]          # shards this rank will use
+        wanted_by = [dst for dst in order if not skips(rank, dst)]      # ranks that will use OUR shard
         ops = [dist.P2POp(dist.isend, cur_buf, peer(dst), group) for dst in wanted_by]
         ops += [dist.P2POp(dist.irecv, rbufs[src], peer(src), group) for src in need]
         reqs = dist.batch_isend_irecv(ops) if ops else []
@@ -189,7 +259,11 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
         for src in need:
             consume(_views_like(rbufs[src], cur), src)
 
-    o_acc, lse = state
+    if zigzag:
+        o_acc = torch.cat([zstate["lo"][0], zstate["hi"][0]], dim=2)
+        lse = torch.cat([zstate["lo"][1], zstate["hi"][1]], dim=2)
+    else:
+        o_acc, lse = state
     o = o_acc.to(q.dtype)
     if tensor_layout == "NHD":
         o = o.transpose(1, 2)

@@ -34,6 +34,20 @@ class OracleRingBackend:
             parts["v"], parts["vs"] = v8, vs
         return parts
 
+    def slice_q(self, qstate, r0, r1):
+        per = 32 if self.gran == "per_thread" else 4
+        return {"q": qstate["q"][:, :, r0:r1], "q8": qstate["q8"][:, :, r0:r1],
+                "qs": qstate["qs"][:, :, r0 // 128 * per:-(-r1 // 128) * per], "sm_scale": qstate["sm_scale"]}
+
+    def slice_kv(self, kv, r0, r1):
+        per = 4 if self.gran == "per_thread" else 1
+        out = {"k8": kv["k8"][:, :, r0:r1], "ks": kv["ks"][:, :, r0 // 64 * per:-(-r1 // 64) * per], "km": kv["km"]}
+        if self.pv == "fp16":
+            out["v"] = kv["v"][:, :, r0:r1]
+        else:
+            out["v"], out["vs"] = kv["v"][..., r0:-(-r1 // 64) * 64], kv["vs"]
+        return out
+
     def block_attn(self, qstate, kv, causal):
         q, q8, qs, sm = qstate["q"], qstate["q8"], qstate["qs"], qstate["sm_scale"]
         M, N = q8.shape[2], kv["k8"].shape[2]

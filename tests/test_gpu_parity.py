@@ -288,6 +288,52 @@ def test_ring_steps_on_one_gpu(sa, pv, causal):
     assert (l1.cpu() - ref_lse).abs().max() < 0.06
 
 
+@pytest.mark.parametrize("pv,gran", [("fp16", "per_thread"), ("fp8", "per_warp")])
+def test_zigzag_half_blocks_on_one_gpu(sa, pv, gran):
+    """Causal ring with the zigzag layout (rank r owns chunks r and 2P-1-r), device half: whole-shard quantisation,
+    half-block products on ROW SLICES of the quantized tensors and scale vectors (strided q8/k8/v views through the
+    C ABI), LSE merge -- replayed serially for 3 ranks on one GPU against exact causal attention, and against the
+    public entry point at world size 1."""
+    from oracle import sage_oracle as O
+    from sageattention_amd.ring import HipRingBackend, ring_sageattn, zigzag_merge, zigzag_split
+    torch.manual_seed(5)
+    B, Hq, Hk, D, P = 1, 4, 2, 128, 3
+    N = 256 * P
+    q = torch.randn(B, Hq, N, D, dtype=torch.float16, device="cuda")
+    k = (torch.randn(B, Hk, N, D, device="cuda") + 2 * torch.randn(1, Hk, 1, D, device="cuda")).half()
+    v = torch.randn(B, Hk, N, D, dtype=torch.float16, device="cuda")
+    be = HipRingBackend(pv=pv, qk_quant_gran=gran)
+    n, h = N // P, N // P // 2
+    shards = [be.prepare_kv(zigzag_split(k, P, r), zigzag_split(v, P, r)) for r in range(P)]
+    rng = {"lo": (0, h), "hi": (h, n)}
+    outs, lses = [], []
+    for r in range(P):
+        ql = zigzag_split(q, P, r)
+        qs = be.prepare_q(ql, D ** -0.5)
+        qp = {"lo": be.slice_q(qs, 0, h), "hi": be.slice_q(qs, h, n)}
+        st = {"lo": be.new_state(ql[:, :, :h]), "hi": be.new_state(ql[:, :, h:])}
+        for step in range(P):
+            s = (r - step) % P
+            pairs = ((("lo", "lo", False), ("hi", "lo", False)) if s < r else (("hi", "all", False),) if s > r
+                     else (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True)))
+            for qa, kb, diag in pairs:
+                kv = shards[s] if kb == "all" else be.slice_kv(shards[s], *rng[kb])
+                ob, lb = be.block_attn(qp[qa], kv, diag)
+                st[qa] = be.merge(st[qa], ob, lb)
+        outs.append(torch.cat([st["lo"][0], st["hi"][0]], dim=2))
+        lses.append(torch.cat([st["lo"][1], st["hi"][1]], dim=2))
+    o = zigzag_merge(outs).cpu()
+    lse = zigzag_merge(lses).cpu()
+    ref, ref_lse = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=True, return_lse=True)
+    assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
+    assert (lse - ref_lse).abs().max() < 0.06
+    # world size 1: zigzag == the two halves of one shard
+    o1, l1 = ring_sageattn(q, k, v, is_causal=True, pv=pv, qk_quant_gran=gran, return_lse=True, causal_layout="zigzag")
+    assert (o1.cpu().float() - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert (l1.cpu() - ref_lse).abs().max() < 0.06
+
+
 @pytest.mark.parametrize("shape", [
     # (B, Hq, Hk, M, N, D, causal, layout)
     (1, 2, 2, 1, 1, 64, False, "HND"),       # single token

@@ -31,15 +31,20 @@ def _worker(rank, world, port, cfg, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from ring_cpu_backend import OracleRingBackend
     from sageattention_amd.ring import ring_sageattn
-    B, Hq, Hk, N, D, causal, pv, layout, schedule = cfg
+    B, Hq, Hk, N, D, causal, pv, layout, schedule = cfg[:9]
+    causal_layout = cfg[9] if len(cfg) > 9 else "contiguous"
     q, k, v = _inputs(B, Hq, Hk, N, D)
     n = N // world
     sl = slice(rank * n, (rank + 1) * n)
-    ql, kl, vl = q[:, :, sl], k[:, :, sl], v[:, :, sl]
+    if causal_layout == "zigzag":
+        from sageattention_amd.ring import zigzag_split
+        ql, kl, vl = (zigzag_split(t, world, rank) for t in (q, k, v))
+    else:
+        ql, kl, vl = q[:, :, sl], k[:, :, sl], v[:, :, sl]
     if layout == "NHD":
         ql, kl, vl = (t.transpose(1, 2).contiguous() for t in (ql, kl, vl))
     o, lse = ring_sageattn(ql, kl, vl, tensor_layout=layout, is_causal=causal, return_lse=True,
-                           backend=OracleRingBackend(pv=pv), schedule=schedule)
+                           backend=OracleRingBackend(pv=pv), schedule=schedule, causal_layout=causal_layout)
     if layout == "NHD":
         o = o.transpose(1, 2)
     torch.save({"o": o.contiguous(), "lse": lse}, os.path.join(out_dir, f"r{rank}.pt"))
@@ -84,3 +89,52 @@ def test_ring_matches_full_attention(tmp_path, world, causal, pv, layout, schedu
             st = be.merge(st, ob, lb)
         assert torch.equal(st[0].to(torch.float16), outs[r]["o"]), f"rank {r} output differs from the serial ring"
         assert torch.equal(st[1], outs[r]["lse"])
+
+
+@pytest.mark.parametrize("world,pv,layout,schedule", [(2, "fp16", "HND", "ring"), (3, "fp8", "NHD", "direct"),
+                                                      (2, "fp16", "HND", "direct")])
+def test_zigzag_causal_ring(tmp_path, world, pv, layout, schedule):
+    """Causal attention with the load-balanced zigzag layout (rank r owns chunks r and 2P-1-r): equals exact causal
+    attention over the whole sequence, and equals the same half-block products replayed serially, bit for bit."""
+    from oracle import sage_oracle as O
+    from sageattention_amd.ring import zigzag_merge, zigzag_split
+    cfg = (1, 4, 2, 256 * world, 64, True, pv, layout, schedule, "zigzag")
+    mp.spawn(_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world, join=True)
+    B, Hq, Hk, N, D = cfg[:5]
+    q, k, v = _inputs(B, Hq, Hk, N, D)
+    ref, ref_lse = O.sdpa_fp32(q, k, v, is_causal=True, return_lse=True)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=True) for r in range(world)]
+    o = zigzag_merge([x["o"] for x in outs]).float()
+    lse = zigzag_merge([x["lse"] for x in outs])
+    assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
+    assert (lse - ref_lse).abs().max() < 0.06
+
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ring_cpu_backend import OracleRingBackend
+    be = OracleRingBackend(pv=pv)
+    n, h = N // world, N // world // 2
+    shards = [be.prepare_kv(zigzag_split(k, world, r), zigzag_split(v, world, r)) for r in range(world)]
+    work = []
+    for r in range(world):
+        ql = zigzag_split(q, world, r)
+        qs = be.prepare_q(ql, D ** -0.5)
+        qp = {"lo": be.slice_q(qs, 0, h), "hi": be.slice_q(qs, h, n)}
+        st = {"lo": be.new_state(ql[:, :, :h]), "hi": be.new_state(ql[:, :, h:])}
+        rng = {"lo": (0, h), "hi": (h, n)}
+        blocks = 0.0
+        for step in range(world):
+            s = (r - step) % world
+            pairs = ((("lo", "lo", False), ("hi", "lo", False)) if s < r else (("hi", "all", False),) if s > r
+                     else (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True)))
+            for qa, kb, diag in pairs:
+                kv = shards[s] if kb == "all" else be.slice_kv(shards[s], *rng[kb])
+                ob, lb = be.block_attn(qp[qa], kv, diag)
+                st[qa] = be.merge(st[qa], ob, lb)
+                blocks += (2.0 if kb == "all" else 1.0) * (0.5 if diag else 1.0)
+        work.append(blocks)
+        o_ser = torch.cat([st["lo"][0], st["hi"][0]], dim=2).to(torch.float16)
+        assert torch.equal(o_ser, outs[r]["o"]), f"rank {r} output differs from the serial replay"
+        assert torch.equal(torch.cat([st["lo"][1], st["hi"][1]], dim=2), outs[r]["lse"])
+    assert len(set(work)) == 1, f"zigzag must balance the half-block products across ranks, got {work}"
