@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--pv", default=None, choices=["fp16", "fp8"], help="override the PV precision of the workload")
     ap.add_argument("--causal", default=None, type=int, choices=[0, 1], help="override the workload's causal flag")
     ap.add_argument("--schedule", default="direct", choices=["direct", "ring"], help="N>1: KV exchange schedule")
+    ap.add_argument("--sp", default="ring", choices=["ring", "ulysses"], help="N>1: sequence-parallel scheme (ring = "
+                    "BASELINE configs[4]; ulysses = head-parallel all-to-all, SURVEY 8 f4)")
     ap.add_argument("--causal-layout", default="zigzag", choices=["zigzag", "contiguous"],
                     help="N>1 causal: zigzag half-blocks (balanced, default) or contiguous shards")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (default); gloo only to "
@@ -136,10 +138,17 @@ def main():
         k = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
         v = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
 
-        def step():
-            return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant, schedule=args.schedule,
-                                      causal_layout=args.causal_layout)
-        parallelism = f"seq-parallel{world}-{args.schedule}" + (f"-{args.causal_layout}" if causal else "")
+        if args.sp == "ulysses":
+            from sageattention_amd import ulysses
+
+            def step():
+                return ulysses.ulysses_sageattn(q, k, v, is_causal=causal, pv=variant, qk_quant_gran=args.gran)
+            parallelism = f"ulysses{world}"
+        else:
+            def step():
+                return ring.ring_sageattn(q, k, v, is_causal=causal, pv=variant, schedule=args.schedule,
+                                          causal_layout=args.causal_layout)
+            parallelism = f"seq-parallel{world}-{args.schedule}" + (f"-{args.causal_layout}" if causal else "")
     else:
         q = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
         k = torch.randn(B, H, N, D, dtype=torch.float16, device=dev)
