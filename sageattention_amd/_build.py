@@ -14,6 +14,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("sage_quant.hip", ["-ffp-contract=off"]),
     ("sage_attn.hip", ["-fno-slp-vectorize"]),  # packed f32 VALU is slower beside MFMAs
+    ("sage_attn_w64.hip", ["-fno-slp-vectorize"]),
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
 ]
@@ -65,7 +66,8 @@ def build_variant(out: str, extra_flags, verbose: bool = False) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "sage_common.h"), os.path.join(HERE, "..", "include", "sageattn_hip.h")]
+    hdrs = [os.path.join(CSRC, "sage_common.h"), os.path.join(CSRC, "sage_attn_common.h"),
+            os.path.join(HERE, "..", "include", "sageattn_hip.h")]
     objs = []
     procs = []
     for src, extra in SOURCES:

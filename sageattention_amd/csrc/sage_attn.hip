@@ -17,127 +17,9 @@
 //
 // Roofline: MFMA (4*M*N*D flop per (b,h); half int8 at 2x the fp16 rate), VALU/exp2 co-limited.
 // Algorithmic HBM bytes per (b,h): M*D (Q) + N*D (K) + 2*N*D (V fp16) + 2*M*D (O) + scales.
-#include <type_traits>
-#include "sage_common.h"
+#include "sage_attn_common.h"
 
 namespace sage {
-
-struct AttnParams {
-  const int8_t* q; int64_t qsb, qsh, qsn;
-  const int8_t* k; int64_t ksb, ksh, ksn;
-  const uint8_t* v; int64_t vsb, vsh, vsn;  // byte pointer; strides in ELEMENTS of v's dtype
-  uint16_t* o; int64_t osb, osh, osn;
-  const float* q_scale; const float* k_scale; const float* v_scale; const float* v_mean;
-  float* lse;
-  int B, Hq, Hk, M, N;
-  int nqb;      // query blocks per (b,h)
-  int gq, gk;   // scales per (b,h)
-  int qgran, blkq, warpq;
-  float logit_mult;
-  int out_bf16;
-  // varlen (packed sequences, core.py:363-477): when cu_q/cu_k are set, "batch" b is sequence b, its rows are
-  // [cu[b], cu[b+1]) of the packed [total, H, D] tensors (stride_b unused) and p.M / p.N are the maximum lengths
-  const int* cu_q;
-  const int* cu_k;
-  // fused Q quantizer: when q_f16 is set, q/q_scale are ignored and every wave quantizes its own 32 query rows in the
-  // prologue (per_warp: CUDA numerics, per_thread: Triton numerics -- the pairings of core.py:621-624); km (optional,
-  // [B,Hk,D] in q's dtype) yields the LSE correction q.km and lse then receives the FINAL natural-log LSE (core.py:651)
-  const uint16_t* q_f16;
-  const uint16_t* km;
-  int q_bf16;
-  float sm_scale;
-  // attn_mask of sageattn_qk_int8_pv_fp16_triton (core.py:306-318; kernels attn_qk_int8_per_block.py:33-52):
-  // [B,H,M,N] view with element strides (0 = broadcast); kind 1 = bool (False -> -1e6), 2 = fp16, 3 = bf16 (added to
-  // the base-2 logits, exactly as the reference adds it after its sm_scale*log2e scaling)
-  const uint8_t* mask;
-  int64_t msb, msh, msm, msn;
-  int mask_kind;
-};
-
-// v_max_f32 on values that are never signalling NaNs: fmaxf() makes hipcc canonicalise both operands first
-// (v_max_f32 x, x, x), two extra instructions on a kernel bound by the vector issue port
-__device__ __forceinline__ float max_raw(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-#else
-  return a > b ? a : b;
-#endif
-}
-__device__ __forceinline__ float swap_max(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float swap_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// 16 bytes per lane, buffer -> LDS without passing through VGPRs (buffer_load_dwordx4 ... offen lds).
-// Issued through inline asm ON PURPOSE: hipcc would otherwise treat the copy as a store that may alias every later
-// LDS read and drain it with s_waitcnt vmcnt(0) a few instructions after issue.  Here nothing waits for it until
-// dma_wait_all() in front of the workgroup barrier that publishes the tile, a whole iteration later.
-// `lds_off` = byte offset of the wave's 1 KiB destination inside the workgroup's LDS (wave-uniform; lane l lands at
-// +16*l), `rsrc` = buffer descriptor (4 uniform dwords), `voffset` per lane, `soffset` uniform.
-__device__ __forceinline__ void lds_dma16(v4i rsrc, unsigned lds_off, int voffset, int soffset) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voffset), "s"(rsrc), "s"(lds_off), "s"(soffset)
-      : "memory");
-#endif
-}
-__device__ __forceinline__ void dma_wait_all() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-// raw buffer descriptor as 4 provably wave-uniform dwords (gfx950: word3 = 0x00020000)
-__device__ __forceinline__ v4i make_rsrc(const void* base, unsigned num_bytes) {
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  v4i r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
-  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)num_bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-
-// Loads through the scalar cache (s_load, lgkmcnt) for wave-uniform addresses of read-only data: the constant
-// address space cast is what lets hipcc pick SMEM; hidden from the host pass.
-__device__ __forceinline__ float4 uniform_load4(const float* ptr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const v4f v = *(const __attribute__((address_space(4))) v4f*)(ptr);
-  return make_float4(v[0], v[1], v[2], v[3]);
-#else
-  return make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-}
-__device__ __forceinline__ float uniform_load1(const float* ptr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return *(const __attribute__((address_space(4))) float*)(ptr);
-#else
-  return 0.f;
-#endif
-}
-
-template <int D>
-__device__ __forceinline__ int k_swz(int row) {
-  // 16-B chunk XOR that makes the ds_read_b128 A-fragment reads conflict free
-  if constexpr (D == 128) return (row >> 1) & 7; else return (row >> 2) & 3;
-}
-template <int D>
-__device__ __forceinline__ int v_win_swz(int row) {
-  // 64-B window XOR for the fp16 V tile so that the 4 rows of a tr-read land on 4 windows
-  if constexpr (D == 128) return row & 3; else return (row >> 1) & 1;
-}
 
 // PV_FP8 = false: V fp16 [N][D] row major (bf16 converted on the fly), PV on v_mfma_f32_32x32x16_f16.
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
@@ -410,8 +292,9 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // per-lane partial row sum of the UNROUNDED p in fp32 on the VALU (the lane's 32 of the row's 64 keys per tile;
   // the two lane halves are added once in the epilogue), as the reference's Triton kernels and its fp8 CUDA kernel
   // (attn_qk_int8_per_block.py:55-60; ComputeUnit::kCudaCore, sm89_*.cu:148).  A ones-row MFMA that sums the
-  // rounded P (the reference's fp16 CUDA trick, attn_utils.cuh:543-547) was measured 3 % slower here: the chip is
-  // power limited and four extra 32x32x16 MFMAs per tile cost more clock than 32 v_add_f32.
+  // rounded P (the reference's fp16 CUDA trick, attn_utils.cuh:543-547) was measured slower in every configuration
+  // (head_dim 128 fp16 -3 %, fp8 -0.7 %; head_dim 64 fp16 -9 %, fp8 -7 %): the chip is power limited and an extra MFMA
+  // per P operand costs more clock than the 32 v_add_f32 it replaces.
   float l_run = 0.f;
   // The int32 accumulator of S^T starts at the BIT PATTERN of 1.5*2^23: for |S| < 2^22 (|S| <= 128*127^2) the
   // accumulated integer, reinterpreted as fp32, IS the float 12582912 + S exactly, so the logit needs no
@@ -758,9 +641,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       const char* const vb = v_lds + PAR * VBYTES;
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
+#ifdef SAGE_ABL_NOLDSK
+        return qf[i % KS];  // timing-only ablation: no K fragment reads
+#endif
         return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
       };
       auto v_frag = [&](const int q, const int dt) __attribute__((always_inline)) -> v8h {
+#ifdef SAGE_ABL_NOLDSV
+        return __builtin_bit_cast(v8h, qf[(q + dt) % KS]);  // timing-only ablation: no V fragment reads
+#endif
         const char* base = vb + 16 * q * (2 * D) + v_rd[dt];
         const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
         const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
@@ -980,6 +869,7 @@ static bool t_ok(const sage_tensor* t, int align_elems) {
 }
 
 int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
+int g_w64 = 0;              // SAGE_TUNE_W64: 0 = default choice, 1 = force the 64-rows-per-wave kernel where it applies, -1 = never
 
 // shared argument handling of the two attention entry points
 static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
@@ -1034,6 +924,9 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
   // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
+  // 64-rows-per-wave kernel (sage_attn_w64.hip): D = 128, fp16 V, dense, int8 q
+  const bool w64_ok = D == 128 && !pv_fp8 && !vb && !cu_q && !mask && !fusedq && !g_nwaves_override;
+  if (w64_ok && g_w64 > 0) return launch_attn_w64(p, D, is_causal, kthread, pv_fp8, st);
   const int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
   p.nqb = (M + nw * 32 - 1) / (nw * 32);
 #define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
@@ -1050,6 +943,11 @@ extern "C" int sage_set_tuning(int key, int value) {
   if (key == SAGE_TUNE_NWAVES) {
     if (value != 0 && value != 4 && value != 8) return SAGE_ERR_INVALID_ARGUMENT;
     g_nwaves_override = value;
+    return SAGE_OK;
+  }
+  if (key == SAGE_TUNE_W64) {
+    if (value < -1 || value > 1) return SAGE_ERR_INVALID_ARGUMENT;
+    g_w64 = value;
     return SAGE_OK;
   }
   return SAGE_ERR_INVALID_ARGUMENT;

@@ -288,6 +288,46 @@ def test_ring_steps_on_one_gpu(sa, pv, causal):
     assert (l1.cpu() - ref_lse).abs().max() < 0.06
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Hq, Hk, M, N, causal, gran, layout)
+    (1, 4, 4, 512, 512, False, "per_thread", "HND"),
+    (2, 4, 2, 300, 700, False, "per_warp", "NHD"),     # ragged, GQA, strided heads
+    (1, 2, 2, 1000, 1000, True, "per_thread", "HND"),  # causal, ragged last block
+    (1, 6, 3, 64, 1300, True, "per_warp", "HND"),      # fewer rows than one 256-row workgroup
+])
+def test_w64_kernel_matches_general_kernel(sa, shape):
+    """The opt-in 64-rows-per-wave kernel (sage_attn_w64.hip, SAGE_TUNE_W64) computes the same operator as the default
+    kernel: same quantized operands in, outputs equal to within one fp16 rounding of the lazily rescaled accumulators
+    (the two sub-tiles of a wave rescale together, which may move a row's running max by less than the lazy threshold),
+    LSE equal to 1e-5."""
+    from sageattention_amd import _lib as L
+    B, Hq, Hk, M, N, causal, gran, layout = shape
+    D = 128
+    torch.manual_seed(17)
+    mk = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
+    q = torch.randn(mk(Hq, M), dtype=torch.float16, device="cuda")
+    k = (torch.randn(mk(Hk, N), device="cuda") + 1.5).half()
+    v = torch.randn(mk(Hk, N), dtype=torch.float16, device="cuda")
+    lib = L.lib()
+    try:
+        assert lib.sage_set_tuning(1, -1) == 0
+        o0, l0 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=layout, is_causal=causal, qk_quant_gran=gran,
+                                                  return_lse=True)
+        assert lib.sage_set_tuning(1, 1) == 0
+        sa.core.FUSE_Q_QUANT, keep = False, sa.core.FUSE_Q_QUANT   # the w64 kernel takes int8 q
+        try:
+            o1, l1 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=layout, is_causal=causal,
+                                                      qk_quant_gran=gran, return_lse=True)
+        finally:
+            sa.core.FUSE_Q_QUANT = keep
+    finally:
+        lib.sage_set_tuning(1, 0)
+    assert torch.isfinite(o1.float()).all()
+    assert (o1.float() - o0.float()).abs().max() <= 2e-3
+    assert calc_diff(o1.float().cpu(), o0.float().cpu()) < 1e-6
+    assert (l1 - l0).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize("pv,gran", [("fp16", "per_thread"), ("fp8", "per_warp")])
 def test_zigzag_half_blocks_on_one_gpu(sa, pv, gran):
     """Causal ring with the zigzag layout (rank r owns chunks r and 2P-1-r), device half: whole-shard quantisation,

@@ -12,12 +12,14 @@ ap.add_argument("--wl", default="c3")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--data", default="randn", choices=["randn", "zeros"], help="zeros: DVFS probe (cdna guide rule 25)")
+ap.add_argument("--pv", default="fp16", choices=["fp16", "fp8"])
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
                       "c2c": (4, 32, 2048, 64, True), "c16k": (2, 32, 16384, 128, False),
                       "d64_8k": (4, 32, 8192, 64, False), "c3s": (1, 32, 8192, 128, False), "c3xs": (1, 8, 8192, 128, False),
-                      "c3l": (8, 32, 8192, 128, False)}[a.wl]
+                      "c3l": (8, 32, 8192, 128, False),
+                      "c4": (4, 32, 16384, 128, True)}[a.wl]
 torch.manual_seed(0)
 q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
 k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
@@ -27,6 +29,9 @@ if a.data == "zeros":
 km = sa.quant.k_mean(k)
 q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
 o = torch.empty_like(q)
+if a.pv == "fp8":
+    v8, vs, _ = sa.quant.per_channel_fp8(v, tensor_layout="HND", smooth_v=False)
+    vd = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(1), v8.stride(2))
 ref = None
 variants = []
 for spec in a.libs:
@@ -35,10 +40,19 @@ for spec in a.libs:
     for name, (res, args) in L.SIGNATURES.items():
         if hasattr(l, name):
             fn = getattr(l, name); fn.restype, fn.argtypes = res, args
-    variants.append((spec, l, int(nw) if nw else 0))
+    variants.append((spec, l, nw if nw == "w64" else (int(nw) if nw else 0)))
 st = torch.cuda.current_stream().cuda_stream
 def run(l, nw):
-    l.sage_set_tuning(0, nw)
+    if nw == "w64":
+        l.sage_set_tuning(0, 0); l.sage_set_tuning(1, 1)
+    else:
+        l.sage_set_tuning(0, nw); l.sage_set_tuning(1, -1)
+    if a.pv == "fp8":
+        r = l.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, L.desc(o, "HND"), 0, qs.data_ptr(),
+                                      ks.data_ptr(), vs.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
+                                      D ** -0.5, 0, st)
+        assert r == 0, r
+        return
     r = l.sage_attn_qk_int8_pv_f16(L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(v, "HND"), 0, L.desc(o, "HND"), 0,
                                    qs.data_ptr(), ks.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
                                    D ** -0.5, 0, st)

@@ -84,6 +84,47 @@ __global__ void k_mfma_fill(long long* out, float seed) {
   if (s == 12345.678f) out[1] = 1;
 }
 
+// MFMA + NV v_add_f32 + NK ds_read_b128 + NT ds_read_b64_tr_b16 per gap (reads are never waited for inside the loop)
+template <int NV, int NK, int NT>
+__global__ void k_mfma_lds(long long* out, float seed) {
+  __shared__ __attribute__((aligned(16))) char lds[65536];
+  for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = seed;
+  __syncthreads();
+  v16f acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = seed;
+  v8h a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (_Float16)seed; b[e] = (_Float16)(seed + e); }
+  float r[8];
+  for (int i = 0; i < 8; ++i) r[i] = seed + i;
+  float x = seed * 0.5f, y = seed * 0.25f;
+  const unsigned addr = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;  // conflict-free linear image
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  typedef int v2i_t __attribute__((ext_vector_type(2)));
+  v4i_t kk[3];
+  v2i_t tt[3];
+  long long t0 = clock64();
+  for (int i = 0; i < REP; ++i) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(b));
+#pragma unroll
+      for (int f = 0; f < NK; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kk[f]) : "v"(addr), "n"(f * 8192));
+#pragma unroll
+      for (int f = 0; f < NT; ++f) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tt[f]) : "v"(addr), "n"(f * 8192 + 32768));
+#pragma unroll
+      for (int f = 0; f < NV; ++f) asm volatile("v_add_f32 %0, %1, %2" : "+v"(r[f & 7]) : "v"(x), "v"(y));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+  }
+  long long t1 = clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+  float s = 0;
+  for (int i = 0; i < 4; ++i) s += acc[i][0];
+  for (int i = 0; i < 8; ++i) s += r[i];
+  if (s == 12345.678f) out[1] = 1;
+}
+
 template <typename F>
 static double run(F kern, int threads, long long* d_out, double per) {
   long long h = 0;
@@ -127,5 +168,15 @@ int main() {
   MF(3, 4, "v_pk_add_f16") MF(3, 8, "v_pk_add_f16")
   MF(4, 4, "v_dot2c_f32_f16") MF(4, 8, "v_dot2c_f32_f16")
   MF(5, 4, "v_max3_i32") MF(5, 8, "v_max3_i32")
+#define ML(NV, NK, NT)                                                                        \
+  {                                                                                           \
+    double t1 = run(k_mfma_lds<NV, NK, NT>, 256, d_out, (double)REP * 4);                     \
+    double t2 = run(k_mfma_lds<NV, NK, NT>, 512, d_out, (double)REP * 4);                     \
+    printf("  v_add=%d b128=%d tr_b64=%d  ticks/MFMA: 1 wave %8.3f   2 waves %8.3f\n", NV, NK, NT, t1, t2); \
+  }
+  printf("== one MFMA + NV v_add_f32 + NK ds_read_b128 + NT ds_read_b64_tr_b16 per gap\n");
+  ML(0, 0, 0) ML(0, 1, 0) ML(0, 2, 0) ML(0, 0, 2) ML(0, 0, 3)
+  ML(4, 0, 0) ML(4, 1, 0) ML(4, 2, 0) ML(4, 0, 2) ML(4, 0, 3) ML(4, 1, 2)
+  ML(6, 0, 0) ML(6, 1, 0) ML(6, 0, 2) ML(6, 1, 2)
   return 0;
 }
