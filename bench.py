@@ -214,9 +214,10 @@ def main():
             # HBM bytes per launch from the committed PMC passes of this kernel on this workload (separate
             # FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", f"r01_attn_{wl}_final_pmc.json")
-            if os.path.exists(pmc):
-                c = json.load(open(pmc))
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_attn_{wl}_pmc.json")))  # latest round last
+            if cands:
+                c = json.load(open(cands[-1]))
                 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                     traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
             out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": peak, "unit": "TFLOP/s",

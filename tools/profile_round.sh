@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profiles of one round, run ON THE GPU BOX from the repo root:  bash tools/profile_round.sh <tag>   (e.g. r01b)
+# Kernel-trace statistics of bench.py for C2/C3/C4, then separate PMC passes of the attention kernel alone at C3
+# (counters never share a run with the trace; FETCH_SIZE / WRITE_SIZE in their own passes -- MI355X_MICROARCH.md).
+set -e -o pipefail
+TAG=${1:-r01}
+R=$(pwd)
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for wl in c3 c2 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-fa2 > $OUT/kt_$wl.log 2>&1
+  cp $(ls $OUT/kt_$wl/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${wl}_kernel_stats.csv
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $OUT/pmc_write -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/pmc_clk -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc_clk.log 2>&1 || true
+python3 $R/tools/pmc_summary.py attn_i8_kernel $OUT/${TAG}_attn_c3_pmc.json $OUT/pmc1 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_clk
