@@ -72,18 +72,20 @@ struct QuantParams {
   int dot_group;
   int N, G;          // rows, scales per (b,h)
   int gran, is_key;  // sage_qk_gran, K-side grouping of per_thread
-  int warp;          // rows per warp group
+  int warp;          // rows per warp group (16, 32, 64 or 128)
+  int warp_shift;    // log2(warp): the group maps run per row and must not cost an integer division
   float mult;
   int rounding;
   const int* cu;  // varlen: sequence b = rows [cu[b], cu[b+1]) of the packed tensor (stride_b unused); N = max length
 };
 
-__device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp) {
+__device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp_shift) {
   // group-id maps: per_block: all rows of the workgroup; per_warp: lr/warp; per_thread:
   // triton/quant_per_thread.py:27-36 (Q: r%8) and :73-80 (K: (r%8)/2).
   if (gran == SAGE_GRAN_PER_BLOCK) return 0;
-  if (gran == SAGE_GRAN_PER_WARP) return lr / warp;
-  return is_key ? (lr / warp) * 4 + (lr % 8) / 2 : (lr / warp) * 8 + lr % 8;
+  const int w = lr >> warp_shift;
+  if (gran == SAGE_GRAN_PER_WARP) return w;
+  return is_key ? w * 4 + ((lr & 7) >> 1) : w * 8 + (lr & 7);
 }
 
 template <int D, int BLK, bool BF16>
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
       if (tc == 0 && valid) p.dot_out[((int64_t)b * H + h) * p.N + row] = dot;
     }
     float amax = 0.f;
+    const float mult_row = valid ? p.mult : 0.f;  // rows past the end contribute zeros (finite inputs: raw is 0 there)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = xf[i][j];
@@ -154,20 +157,19 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
         v = v - mean_f[j];
         if (p.rounding == SAGE_ROUND_TRITON) v = round_to_elem<BF16>(v);  // torch `k - km` in the input dtype
       }
-      v = v * p.mult;
-      if (!valid) v = 0.f;
+      v = v * mult_row;
       xf[i][j] = v;
       amax = fmaxf(amax, fabsf(v));
     }
 #pragma unroll
     for (int o = 1; o < TPR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (tc == 0) atomicMax(&gmax[group_of_row(lr, p.gran, p.is_key, p.warp)], __float_as_uint(amax));
+    if (tc == 0) atomicMax(&gmax[group_of_row(lr, p.gran, p.is_key, p.warp_shift)], __float_as_uint(amax));
   }
   __syncthreads();
 
   const int groups_per_blk = p.gran == SAGE_GRAN_PER_BLOCK ? 1
-                             : p.gran == SAGE_GRAN_PER_WARP ? BLK / p.warp
-                                                            : (BLK / p.warp) * (p.is_key ? 4 : 8);
+                             : p.gran == SAGE_GRAN_PER_WARP ? BLK >> p.warp_shift
+                                                            : (BLK >> p.warp_shift) * (p.is_key ? 4 : 8);
   const float eps = (p.gran == SAGE_GRAN_PER_THREAD) ? 0.0000001f : 0.f;
   if (threadIdx.x < groups_per_blk) {
     const float a = __uint_as_float(gmax[threadIdx.x]);
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   for (int i = 0; i < NP; ++i) {
     const int lr = i * RPP + tr;
     const int row = blk * BLK + lr;
-    const float a = __uint_as_float(gmax[group_of_row(lr, p.gran, p.is_key, p.warp)]);
+    const float a = __uint_as_float(gmax[group_of_row(lr, p.gran, p.is_key, p.warp_shift)]);
     int q[8];
     if (p.rounding == SAGE_ROUND_TRITON) {
       // q = trunc(x/sc + 0.5*sign) with an IEEE division (quant_per_block.py:42-44).  The division costs ~10 VALU
@@ -194,10 +196,10 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float ya = xf[i][j] * r;
-        const float z = fabsf(ya) + 0.5f;
-        const float f = z - floorf(z);
-        near |= (f < 6.1035156e-5f) | (f > 1.0f - 6.1035156e-5f);
-        q[j] = (int)(ya + (ya >= 0.f ? 0.5f : -0.5f));
+        // fractional part of |ya| + 0.5 within 2^-14 of 0 or 1  <=>  |fract - 0.5| > 0.5 - 2^-14  (v_fract, v_sub, v_cmp)
+        const float f = __builtin_amdgcn_fractf(fabsf(ya) + 0.5f);
+        near |= fabsf(f - 0.5f) > 0.5f - 6.1035156e-5f;
+        q[j] = (int)(ya + __builtin_copysignf(0.5f, ya));
       }
       if (__builtin_amdgcn_ballot_w64(near || !(fabsf(r) < 3.0e38f)) != 0) {
 #pragma unroll
@@ -311,6 +313,7 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   p.scale = scale; p.dot_vec = (const uint16_t*)lse_dot_vec; p.dot_out = lse_dot; p.dot_group = dot_group > 0 ? dot_group : 1;
   p.cu = cu;
   p.N = N; p.G = nblk * gpb; p.gran = gran; p.is_key = is_key ? 1 : 0; p.warp = warp; p.mult = mult; p.rounding = rounding;
+  p.warp_shift = warp == 16 ? 4 : warp == 32 ? 5 : warp == 64 ? 6 : 7;
   dim3 grid(nblk, H, B);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(DD, BL, BF) hipLaunchKernelGGL((quant_qk_int8_kernel<DD, BL, BF>), grid, dim3(256), 0, st, p)
