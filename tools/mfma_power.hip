@@ -63,6 +63,89 @@ __global__ __launch_bounds__(512) void k_loop(const int* __restrict__ src, float
   if (r == 12345.678f) out[t] = r;
 }
 
+
+// Attention-like instruction mix per loop iteration (1/8 of a 32x64 wave-tile of the kernel): MFMAs of the given shape
+// family + 18 VALU (4 v_exp_f32, 4 v_fma_f32, 4 v_add_f32, 2 v_cvt_pk_f16_f32, 2 v_max3_i32, 2 v_mul_f32) + 5 LDS reads
+// (1 ds_read_b128, 4 ds_read_b64_tr_b16), random data.  SMALL = false: 1 x i8 32x32x32 + 2 x f16 32x32x16;
+// SMALL = true: 2 x i8 16x16x64 + 4 x f16 16x16x32 (same flops).  What matters is the wall-clock ratio of the two.
+template <bool SMALL>
+__global__ __launch_bounds__(512) void k_mix(const int* __restrict__ src, float* out) {
+  __shared__ __attribute__((aligned(16))) int lds[8192];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = src[(t + i * 7) & 0xfffff];
+  __syncthreads();
+  v4i a4[2], b4[2];
+  for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 4; ++e) { a4[i][e] = src[(t * 16 + i * 4 + e) & 0xfffff]; b4[i][e] = src[(t * 16 + 8 + i * 4 + e) & 0xfffff]; }
+  v8h h0 = __builtin_bit_cast(v8h, a4[0]), h1 = __builtin_bit_cast(v8h, b4[1]);
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = -0.001f * (float)((src[(t + i) & 0xfffff] & 0xffff) + 1);
+  float sc = 0.999f, cc = -0.5f, sum = 0.f;
+  int mx = 0;
+  const unsigned addr = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;
+  v16i si = {}; v16f of[2] = {};
+  v4i s4[2] = {}; v4f o4[4] = {};
+  v4i kk; typedef int v2i_t __attribute__((ext_vector_type(2))); v2i_t tt[4];
+  for (int it = 0; it < REP; ++it) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(kk) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(tt[0]) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(tt[1]) : "v"(addr));
+    if (SMALL) {
+      asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(s4[0]) : "v"(a4[0]), "v"(b4[0]));
+      asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(s4[1]) : "v"(a4[1]), "v"(b4[0]));
+    } else {
+      asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(si) : "v"(a4[0]), "v"(b4[0]));
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float e0, e1; int pk;
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(x[2 * u]), "v"(sc), "v"(cc));
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(x[2 * u + 1]), "v"(sc), "v"(cc));
+      asm volatile("v_exp_f32 %0, %0" : "+v"(e0));
+      asm volatile("v_exp_f32 %0, %0" : "+v"(e1));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(e0));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(e1));
+      asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(e0), "v"(e1));
+      asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(mx) : "v"(a4[u][0]), "v"(b4[u][1]));
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[4 + u]) : "v"(sc));
+      if (SMALL) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(o4[2 * u]) : "v"(h0), "v"(h1));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(o4[2 * u + 1]) : "v"(h1), "v"(h0));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(of[u]) : "v"(h0), "v"(h1));
+      }
+      if (u == 0) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:24576" : "=v"(tt[2]) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:28672" : "=v"(tt[3]) : "v"(addr));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float r = sum + (float)mx + x[4] + x[5] + (float)si[0] + of[0][0] + of[1][1] + (float)s4[0][0] + (float)s4[1][1] + o4[0][0] + o4[1][0] +
+            o4[2][0] + o4[3][0] + (float)kk[0] + (float)tt[0][0] + (float)tt[1][0] + (float)tt[2][0] + (float)tt[3][0];
+  if (r == 12345.678f) out[t] = r;
+}
+
+template <bool SMALL>
+static void run_mix(const char* name, const int* d_src, float* d_out) {
+  const int blocks = 256 * 4, threads = 512;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_mix<SMALL>, dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  const int launches = 8;
+  for (int w = 0; w < launches; ++w) hipLaunchKernelGGL(k_mix<SMALL>, dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double waves = (double)blocks * threads / 64;
+  const double flops = waves * REP * (2.0 * 32 * 32 * 32 + 2 * 2.0 * 32 * 32 * 16) * launches;
+  printf("%-44s %8.3f ms  %8.1f TFLOP/s\n", name, ms, flops / (ms * 1e-3) / 1e12);
+}
+
 template <int KIND>
 static void run(const char* name, const int* d_src, float* d_out, double flop_per_wave_iter) {
   const int blocks = 256 * 4, threads = 512;  // 2 waves per SIMD, 4 workgroups queued per CU
@@ -98,5 +181,7 @@ int main(int argc, char** argv) {
   run<1>("i8  16x16x64 (x4)", d_src, d_out, 4.0 * 2 * 16 * 16 * 64);
   run<2>("f16 32x32x16 (x2)", d_src, d_out, 2.0 * 2 * 32 * 32 * 16);
   run<3>("f16 16x16x32 (x4)", d_src, d_out, 4.0 * 2 * 16 * 16 * 32);
+  run_mix<false>("attention-like mix, 32x32 MFMAs", d_src, d_out);
+  run_mix<true>("attention-like mix, 16x16 MFMAs", d_src, d_out);
   return 0;
 }
