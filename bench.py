@@ -223,7 +223,12 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(k_tflops / peak, 4), "traffic": traffic,
                                "kernel": f"attn_i8_kernel<D={D}, pv={variant}>",
-                               "kernel_ms": round(k_ms, 4), "flops_per_launch": total_flops}
+                               "kernel_ms": round(k_ms, 4), "flops_per_launch": total_flops,
+                               # context, measured with tools/mfma_power.hip on random operands:
+                               # the chip is power limited under this operator; TFLOP/s of (a) nothing but the
+                               # kernel's MFMAs, (b) a dependency-free loop of its whole instruction mix
+                               "power_limited_context": {"mfma_only": 2180, "instruction_mix": 1477}
+                               if variant == "fp16" and D == 128 else None}
             pre_ms = time_events(lambda: sacore._quant_qk(q, k, sa.quant.k_mean(k), "HND", args.gran, D ** -0.5, 32,
                                                           False, H, H), args.steps, args.warmup)
             # quantizer pre-pass: algorithmic bytes = K read twice (mean, quant) + Q read once + int8 written

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void k_loop(const int* __restrict__ src, float
 // family + 18 VALU (4 v_exp_f32, 4 v_fma_f32, 4 v_add_f32, 2 v_cvt_pk_f16_f32, 2 v_max3_i32, 2 v_mul_f32) + 5 LDS reads
 // (1 ds_read_b128, 4 ds_read_b64_tr_b16), random data.  SMALL = false: 1 x i8 32x32x32 + 2 x f16 32x32x16;
 // SMALL = true: 2 x i8 16x16x64 + 4 x f16 16x16x32 (same flops).  What matters is the wall-clock ratio of the two.
-template <bool SMALL>
+template <bool SMALL, int NTR = 4, int NB128 = 1, int NEXP = 4>
 __global__ __launch_bounds__(512) void k_mix(const int* __restrict__ src, float* out) {
   __shared__ __attribute__((aligned(16))) int lds[8192];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(512) void k_mix(const int* __restrict__ src, float*
   v4i s4[2] = {}; v4f o4[4] = {};
   v4i kk; typedef int v2i_t __attribute__((ext_vector_type(2))); v2i_t tt[4];
   for (int it = 0; it < REP; ++it) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(kk) : "v"(addr));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(tt[0]) : "v"(addr));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(tt[1]) : "v"(addr));
+    if (NB128 > 0) asm volatile("ds_read_b128 %0, %1" : "=v"(kk) : "v"(addr));
+    if (NTR > 0) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(tt[0]) : "v"(addr));
+    if (NTR > 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(tt[1]) : "v"(addr));
     if (SMALL) {
       asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(s4[0]) : "v"(a4[0]), "v"(b4[0]));
       asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(s4[1]) : "v"(a4[1]), "v"(b4[0]));
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(512) void k_mix(const int* __restrict__ src, float*
       float e0, e1; int pk;
       asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(x[2 * u]), "v"(sc), "v"(cc));
       asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(x[2 * u + 1]), "v"(sc), "v"(cc));
-      asm volatile("v_exp_f32 %0, %0" : "+v"(e0));
-      asm volatile("v_exp_f32 %0, %0" : "+v"(e1));
+      if (NEXP > 2 * u) asm volatile("v_exp_f32 %0, %0" : "+v"(e0));
+      if (NEXP > 2 * u + 1) asm volatile("v_exp_f32 %0, %0" : "+v"(e1));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(e0));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(e1));
       asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(e0), "v"(e1));
@@ -115,28 +115,30 @@ __global__ __launch_bounds__(512) void k_mix(const int* __restrict__ src, float*
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(of[u]) : "v"(h0), "v"(h1));
       }
       if (u == 0) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:24576" : "=v"(tt[2]) : "v"(addr));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:28672" : "=v"(tt[3]) : "v"(addr));
+        if (NTR > 2) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:24576" : "=v"(tt[2]) : "v"(addr));
+        if (NTR > 3) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:28672" : "=v"(tt[3]) : "v"(addr));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  for (int i = 0; i < 4; ++i) if (i >= NTR) { tt[i][0] = 0; }
+  if (NB128 == 0) kk[0] = 0;
   float r = sum + (float)mx + x[4] + x[5] + (float)si[0] + of[0][0] + of[1][1] + (float)s4[0][0] + (float)s4[1][1] + o4[0][0] + o4[1][0] +
             o4[2][0] + o4[3][0] + (float)kk[0] + (float)tt[0][0] + (float)tt[1][0] + (float)tt[2][0] + (float)tt[3][0];
   if (r == 12345.678f) out[t] = r;
 }
 
-template <bool SMALL>
+template <bool SMALL, int NTR = 4, int NB128 = 1, int NEXP = 4>
 static void run_mix(const char* name, const int* d_src, float* d_out) {
   const int blocks = 256 * 4, threads = 512;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_mix<SMALL>, dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_mix<SMALL, NTR, NB128, NEXP>), dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
   const int launches = 8;
-  for (int w = 0; w < launches; ++w) hipLaunchKernelGGL(k_mix<SMALL>, dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
+  for (int w = 0; w < launches; ++w) hipLaunchKernelGGL((k_mix<SMALL, NTR, NB128, NEXP>), dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms = 0;
@@ -183,5 +185,9 @@ int main(int argc, char** argv) {
   run<3>("f16 16x16x32 (x4)", d_src, d_out, 4.0 * 2 * 16 * 16 * 32);
   run_mix<false>("attention-like mix, 32x32 MFMAs", d_src, d_out);
   run_mix<true>("attention-like mix, 16x16 MFMAs", d_src, d_out);
+  run_mix<false, 2, 1, 4>("mix 32x32, half the V^T fragment reads", d_src, d_out);
+  run_mix<false, 0, 0, 4>("mix 32x32, no LDS reads", d_src, d_out);
+  run_mix<false, 4, 1, 2>("mix 32x32, half the v_exp_f32", d_src, d_out);
+  run_mix<false, 4, 1, 0>("mix 32x32, no v_exp_f32", d_src, d_out);
   return 0;
 }
