@@ -619,14 +619,93 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     scales_from(kk_nxt, b0, b1);
     kk_nxt = load_kscales(min(j + 2, ntiles - 1));
 #ifdef SAGE_SCHED_COMPILER
-    constexpr bool HAND_PLACED = false;
+    constexpr int HAND_PLACED = 0;
+#elif defined(SAGE_SCHED_COMPILER_FP8)
+    constexpr int HAND_PLACED = PV_FP8 ? 0 : 1;
 #else
-    constexpr bool HAND_PLACED = !PV_FP8;
+    constexpr int HAND_PLACED = PV_FP8 ? 2 : 1;
 #endif
-    if constexpr (!HAND_PLACED) {
+    if constexpr (HAND_PLACED == 0) {
       qk(PAR ^ 1, sb);
       softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
       mx_cur = row_max(sb, b0, b1);
+    } else if constexpr (HAND_PLACED == 2) {
+      // Hand-placed stream, FP8 PV.  The K = 64 MFMA consumes the P of the whole tile, so all of P(j) precedes the P.V
+      // MFMAs; left alone hipcc emits ~110 softmax VALU instructions with the matrix pipe idle and then the 12 MFMAs in
+      // one cluster.  Here: the S(j+1) MFMAs are spread through the computation of the eight P words (4 keys each:
+      // 4 fma, 4 exp2, 2 cvt_pk_fp8; the row-sum adds trail by one word), the V^T fragments are read while the last
+      // words are computed, and the four P.V MFMAs run beside the row max of S(j+1).
+      constexpr int NS = 2 * KS;       // S MFMAs per tile
+      constexpr int WPS = 8 / NS;      // P words per S MFMA (1 at head_dim 128, 2 at 64)
+      const char* const kb = k_lds + (PAR ^ 1) * KBYTES;
+      const char* const vb = v_lds + PAR * VBYTES;
+      const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
+      auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
+        return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
+      };
+      auto s_step = [&](const int i, const v4i a) __attribute__((always_inline)) {
+        const int mt = i / KS, ks = i % KS;
+        sb[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : sb[mt], 0, 0, 0);
+      };
+      auto v_frag8 = [&](const int dt) __attribute__((always_inline)) -> v8i {
+        const char* base = vb + dt * 32 * 64;
+        v8i a;
+        a.s0123 = *reinterpret_cast<const v4i*>(base + v_rd8[0]);
+        a.s4567 = *reinterpret_cast<const v4i*>(base + v_rd8[1]);
+        return a;
+      };
+      v8i pb;
+      float pend[4], psum = 0.f;
+      auto p_word = [&](const int w) __attribute__((always_inline)) {
+        const int mt = w >> 2, e0 = 4 * (w & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool g1 = ((e0 + i) & 2) != 0;
+          pend[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(sa[mt][e0 + i]), g1 ? a1 : a0, g1 ? c1 : c0));
+        }
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[0], pend[1], 0, false);  // OCP e4m3, RNE
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[2], pend[3], pk, true);
+        pb[w] = pk;
+      };
+      auto p_sum = [&]() __attribute__((always_inline)) { psum += pend[0]; psum += pend[1]; psum += pend[2]; psum += pend[3]; };
+#define SAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+      v4i kf = k_frag(0);
+      v8i vf[DT];
+      int si = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        if (w % WPS == 0) {
+          s_step(si, kf);
+          if (si + 1 < NS) kf = k_frag(si + 1);
+          ++si;
+        }
+        if (w > 0) p_sum();
+        p_word(w);
+        if (w == 6) vf[0] = v_frag8(0);
+        if (w == 7 && DT > 1) vf[1] = v_frag8(1);
+        SAGE_FENCE();
+      }
+      p_sum();
+      l_run += psum;
+      // P.V beside the row max of S(j+1)
+      int mxa = sb[0][0], mxb = sb[0][2];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (dt + 2 < DT) vf[dt + 2] = v_frag8(dt + 2);
+        acc_o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[dt], pb, acc_o[dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+        for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
+          const int mt = idx >> 4, e = idx & 15;
+          if (e & 2) mxb = max(mxb, sb[mt][e]); else mxa = max(mxa, sb[mt][e]);
+        }
+        asm volatile("" : "+v"(mxa), "+v"(mxb));
+        SAGE_FENCE();
+      }
+#undef SAGE_FENCE
+      float mx;
+      if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * b0, (__int_as_float(mxb) - kBiasF) * b1);
+      else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
+      mx_cur = swap_max(mx);
     } else {
       // Hand-placed instruction stream (fp16 PV).  The wave issues in order and an MFMA that finds the matrix pipe
       // busy blocks the VALU instructions behind it, so what counts is what sits BETWEEN consecutive MFMAs: about

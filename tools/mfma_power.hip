@@ -148,6 +148,70 @@ static void run_mix(const char* name, const int* d_src, float* d_out) {
   printf("%-44s %8.3f ms  %8.1f TFLOP/s\n", name, ms, flops / (ms * 1e-3) / 1e12);
 }
 
+
+// FP8-PV instruction mix (1/4 of a 32x64 wave-tile): 2 x i8 32x32x32 + 1 x MX-scaled fp8 32x32x64 (unit scales) +
+// 36 VALU (8 v_exp_f32, 8 v_fma_f32, 8 v_add_f32, 4 v_cvt_pk_fp8_f32, 4 v_max3_i32, 4 v_mul_f32) + 4 ds_read_b128.
+typedef int v8i __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void k_mix8(const int* __restrict__ src, float* out) {
+  __shared__ __attribute__((aligned(16))) int lds[8192];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = src[(t + i * 7) & 0xfffff];
+  __syncthreads();
+  v4i a4[2], b4[2];
+  for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 4; ++e) { a4[i][e] = src[(t * 16 + i * 4 + e) & 0xfffff]; b4[i][e] = src[(t * 16 + 8 + i * 4 + e) & 0xfffff]; }
+  v8i f8a, f8b;
+  for (int e = 0; e < 8; ++e) { f8a[e] = src[(t * 8 + e) & 0xfffff] & 0x77777777; f8b[e] = src[(t * 8 + e + 64) & 0xfffff] & 0x77777777; }
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = -0.001f * (float)((src[(t + i) & 0xfffff] & 0xffff) + 1);
+  float sc = 0.999f, cc = -0.5f, sum = 0.f;
+  int mx = 0;
+  const unsigned addr = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;
+  v16i si[2] = {}; v16f of = {};
+  v4i kk[4];
+  for (int it = 0; it < REP; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kk[u]) : "v"(addr), "n"(u * 8192));
+    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(si[0]) : "v"(a4[0]), "v"(b4[0]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float e0, e1; int pk = 0;
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(x[2 * (u & 1)]), "v"(sc), "v"(cc));
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(x[2 * (u & 1) + 1]), "v"(sc), "v"(cc));
+      asm volatile("v_exp_f32 %0, %0" : "+v"(e0));
+      asm volatile("v_exp_f32 %0, %0" : "+v"(e1));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(e0));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(e1));
+      asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(pk) : "v"(e0), "v"(e1));
+      asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(mx) : "v"(a4[u & 1][0]), "v"(pk));
+      asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[4 + (u & 1)]) : "v"(sc));
+      if (u == 1) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(si[1]) : "v"(a4[1]), "v"(b4[1]));
+    }
+    of = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f8a, f8b, of, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float r = sum + (float)mx + x[4] + x[5] + (float)si[0][0] + (float)si[1][1] + of[0] + (float)(kk[0][0] + kk[1][0] + kk[2][0] + kk[3][0]);
+  if (r == 12345.678f) out[t] = r;
+}
+static void run_mix8(const int* d_src, float* d_out) {
+  const int blocks = 256 * 4, threads = 512;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_mix8, dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  const int launches = 8;
+  for (int w = 0; w < launches; ++w) hipLaunchKernelGGL(k_mix8, dim3(blocks), dim3(threads), 0, 0, d_src, d_out);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double waves = (double)blocks * threads / 64;
+  const double flops = waves * REP * (2 * 2.0 * 32 * 32 * 32 + 2.0 * 32 * 32 * 64) * launches;
+  printf("%-44s %8.3f ms  %8.1f TFLOP/s\n", "FP8-PV mix (i8 + MX fp8 32x32x64)", ms, flops / (ms * 1e-3) / 1e12);
+}
+
 template <int KIND>
 static void run(const char* name, const int* d_src, float* d_out, double flop_per_wave_iter) {
   const int blocks = 256 * 4, threads = 512;  // 2 waves per SIMD, 4 workgroups queued per CU
@@ -185,6 +249,7 @@ int main(int argc, char** argv) {
   run<3>("f16 16x16x32 (x4)", d_src, d_out, 4.0 * 2 * 16 * 16 * 32);
   run_mix<false>("attention-like mix, 32x32 MFMAs", d_src, d_out);
   run_mix<true>("attention-like mix, 16x16 MFMAs", d_src, d_out);
+  run_mix8(d_src, d_out);
   run_mix<false, 2, 1, 4>("mix 32x32, half the V^T fragment reads", d_src, d_out);
   run_mix<false, 0, 0, 4>("mix 32x32, no LDS reads", d_src, d_out);
   run_mix<false, 4, 1, 2>("mix 32x32, half the v_exp_f32", d_src, d_out);
