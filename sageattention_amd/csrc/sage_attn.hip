@@ -1005,11 +1005,12 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.q_f16 = fusedq ? (const uint16_t*)q8->data : nullptr;
   p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
-  // measured on MI355X: D=128 -> one 8-wave workgroup per CU; D=64 (164 VGPRs) -> 4-wave workgroups, 3 per CU
   // 64-rows-per-wave kernel (sage_attn_w64.hip): D = 128, fp16 V, dense, int8 q
   const bool w64_ok = D == 128 && !pv_fp8 && !vb && !cu_q && !mask && !fusedq && !g_nwaves_override;
   if (w64_ok && g_w64 > 0) return launch_attn_w64(p, D, is_causal, kthread, pv_fp8, st);
-  const int nw = g_nwaves_override ? g_nwaves_override : (D == 64 ? 4 : 8);
+  // measured on MI355X: D=128 fp16 PV -> one 8-wave workgroup per CU (4-wave: -3 %); D=128 fp8 PV -> two 4-wave
+  // workgroups per CU (+3.6 % non-causal, +5.7 % causal); D=64 (<= 168 VGPRs) -> 4-wave workgroups, 3 per CU
+  const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8) ? 4 : 8);
   p.nqb = (M + nw * 32 - 1) / (nw * 32);
 #define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
   if (nw == 8) return D == 64 ? SAGE_GO(64, 8) : SAGE_GO(128, 8);
