@@ -14,6 +14,7 @@ torch.manual_seed(0)
 q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
 def run(fused, iters):
     core.FUSE_Q_QUANT = fused
+    core.FUSE_Q_MAX_SEQ = 1 << 30  # compare the two paths at every length
     for _ in range(2): fn(q, k, v, is_causal=causal)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
