@@ -235,14 +235,20 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     }
   }
   // K(j) -> K buffer `buf`
-  auto dma_k = [&](const int j, const int buf) __attribute__((always_inline)) {
+  auto dma_k = [&](int j, const int buf) __attribute__((always_inline)) {
+#ifdef SAGE_ABL_SAMETILE
+    j = 0;  // timing-only ablation: every copy re-reads tile 0 (vector-L1 hits): what the L2 latency of the copies costs
+#endif
 #pragma unroll
     for (int i = 0; i < KC; ++i)
       if (KC * T == 64 * KCH || wave * 64 + i * T < 64 * KCH)
         lds_dma16(k_rsrc, (unsigned)(buf * KBYTES + (wave * 64 + i * T) * 16), k_voff[i], j * k_tile_stride);
   };
   // V(j) -> V buffer `buf` (DMA), or -> registers (bf16 path; written to LDS by store_v)
-  auto load_v = [&](const int j, const int buf) __attribute__((always_inline)) {
+  auto load_v = [&](int j, const int buf) __attribute__((always_inline)) {
+#ifdef SAGE_ABL_SAMETILE
+    j = 0;
+#endif
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
       if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;

@@ -13,6 +13,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--data", default="randn", choices=["randn", "zeros"], help="zeros: DVFS probe (cdna guide rule 25)")
 ap.add_argument("--pv", default="fp16", choices=["fp16", "fp8"])
+ap.add_argument("--share-kv", action="store_true", help="latency probe: every head reads the K/V of head 0 (stride 0): all tiles L2 hits")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
@@ -29,8 +30,14 @@ if a.data == "zeros":
 km = sa.quant.k_mean(k)
 q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
 o = torch.empty_like(q)
+if a.share_kv:
+    k8 = k8[:, :1].expand(B, H, N, D)
+    ks = ks[:, :1].expand(B, H, ks.shape[-1]).contiguous()
+    v = v[:, :1].expand(B, H, N, D)
 if a.pv == "fp8":
-    v8, vs, _ = sa.quant.per_channel_fp8(v, tensor_layout="HND", smooth_v=False)
+    v8, vs, _ = sa.quant.per_channel_fp8(v.contiguous(), tensor_layout="HND", smooth_v=False)
+    if a.share_kv:
+        v8 = v8[:, :1].expand(B, H, v8.shape[2], v8.shape[3])
     vd = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(1), v8.stride(2))
 ref = None
 variants = []
