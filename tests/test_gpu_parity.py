@@ -247,6 +247,38 @@ def test_full_size_properties(sa):
         assert (o8.float() - 1).abs().max() < 0.08  # e4m3 P: the fp32 normaliser is not the sum of the rounded P
 
 
+def test_full_size_c4_fp8_causal_properties(sa):
+    """BASELINE configs[3] = (4,32,16384,128), INT8 QK^T + FP8 PV, causal, at full size, through properties that do
+    not need an O(N^2) reference for the whole tensor: (1) V = 1 => O = 1; (2) causality: with K smoothing off, the
+    first half of the output rows does not change by one bit when the second half of K is replaced (keys in the
+    future of every one of those rows; V is left alone because its per-channel FP8 scale spans all tokens);
+    (3) one head equals the oracle."""
+    from oracle import sage_oracle as O
+    torch.manual_seed(4)
+    B, H, N, D = 4, 32, 16384, 128
+    q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    ones = torch.ones_like(v)
+    o1 = sa.sageattn(q, k, ones, is_causal=True)                     # the dispatcher: FP8 PV
+    assert (o1.float() - 1).abs().max() < 0.08
+    del ones, o1
+    oa = sa.sageattn_qk_int8_pv_fp8_cuda(q, k, v, is_causal=True, smooth_k=False)
+    k2 = k.clone()
+    k2[:, :, N // 2:] = torch.randn(B, H, N // 2, D, dtype=torch.float16, device="cuda") * 3
+    ob = sa.sageattn_qk_int8_pv_fp8_cuda(q, k2, v, is_causal=True, smooth_k=False)
+    assert torch.equal(oa[:, :, :N // 2], ob[:, :, :N // 2])
+    assert not torch.equal(oa[:, :, N // 2:], ob[:, :, N // 2:])
+    del k2, ob
+    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(q, k, v, is_causal=True, return_lse=True)
+    sl = (slice(2, 3), slice(17, 18))
+    oo, ol = O.sageattn_oracle(q[sl].cpu(), k[sl].cpu(), v[sl].cpu(), qk_quant_gran="per_thread", is_causal=True, pv="fp8",
+                               return_lse=True)
+    assert (o[sl].cpu().float() - oo.float()).abs().max() < 0.06
+    assert calc_diff(o[sl].cpu().float(), oo.float()) < 1e-3
+    assert (lse[sl].cpu() - ol).abs().max() < 2e-3
+
+
 @pytest.mark.parametrize("pv", ["fp16", "fp8"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_ring_steps_on_one_gpu(sa, pv, causal):
