@@ -307,7 +307,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // v_cvt_f32_i32: t - m = fma(as_float(acc), scale, -(12582912*scale + m)).
   constexpr int kBiasI = 0x4B400000;
   constexpr float kBiasF = 12582912.0f;
-  constexpr int kMaskedI = kBiasI - (1 << 22);  // below every real score
+  // A masked score is the bit pattern of -inf: as an INTEGER it is below every real score (they are ~0x4B400000), so the
+  // integer row max ignores it; as a FLOAT it makes fma(-inf, scale, c) = -inf for any positive scale and exp2 returns
+  // exactly 0 -- no per-element zeroing of p, no mask bits to carry from the S tile to the P tile.
+  constexpr int kMaskedI = (int)0xFF800000u;
   v16i bias;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = kBiasI;
@@ -317,7 +320,22 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // At head_dim 64 a wave that stays within 168 registers runs three to a SIMD; for the FP8-PV and the causal variants
   // the 16 registers are worth more than the moves (measured: fp8 +5 %, causal +7 %; non-causal fp16 -1.5 % without
   // the pin, so that one keeps it).
-  if constexpr (!HAS_MASK && (D == 128 || (!PV_FP8 && !CAUSAL))) asm volatile("" : "+v"(bias));
+  constexpr bool BIAS_RESIDENT = !HAS_MASK && (D == 128 || (!PV_FP8 && !CAUSAL));
+  if constexpr (BIAS_RESIDENT) asm volatile("" : "+v"(bias));
+  // First k-step of an S^T chain: acc = bias + K.Q^T.  The C operand must NOT be a temporary that dies when the MFMA
+  // issues: hipcc then reuses those registers for VALU results after the 7 wait states its hazard table assumes for an
+  // 8-pass MFMA, and on MI355X with three waves per SIMD queueing on the matrix pipe that was measured to corrupt C
+  // (nondeterministic rows at head_dim 64 causal, 81 of 100 runs).  So C is either the resident bias tuple, which
+  // nothing ever writes, or the MFMA's own destination registers initialised in place (C = D).
+  auto mfma_s_first = [&](const v4i a, const v4i b) __attribute__((always_inline)) -> v16i {
+    if constexpr (BIAS_RESIDENT) {
+      return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, bias, 0, 0, 0);
+    } else {
+      v16i acc = bias;
+      asm volatile("" : "+v"(acc));  // the 16 moves land in the accumulator itself
+      return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+    }
+  };
 
   // S^T = K . Q^T for one tile (2 x 32 keys x 32 query rows) out of LDS buffer `kbuf`
   auto qk = [&](const int kbuf, v16i (&s)[2]) __attribute__((always_inline)) {
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         s[mt] = bias; s[mt][0] += kbuf + ks;
 #else
         const v4i a = *reinterpret_cast<const v4i*>(k_lds + kbuf * KBYTES + mt * 32 * D + k_rd[ks]);
-        s[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : s[mt], 0, 0, 0);
+        s[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s[mt], 0, 0, 0);
 #endif
       }
   };
@@ -393,6 +411,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         bits |= run << (16 * mt + 4 * g4);
       }
     return bits;
+  };
+  // sequence end and causal diagonal (the kernels without attn_mask): register e of block mt holds key
+  // 64*j + 32*mt + (e&3) + 8*(e>>2) + 4*hh, allowed iff <= min(N-1, row): one compare against a per-lane limit
+  auto mask_limit = [&](const int j, v16i (&s)[2]) __attribute__((always_inline)) {
+    const int lim = min(N_ - 1, CAUSAL ? row : 0x7fffffff) - (j << 6) - 4 * hh;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[mt][e] = (32 * mt + (e & 3) + 8 * (e >> 2) <= lim) ? s[mt][e] : kMaskedI;
   };
   auto mask_scores = [&](const uint32_t bits, v16i (&s)[2]) __attribute__((always_inline)) {
 #pragma unroll
@@ -493,9 +520,6 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
 #else
         pv = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
 #endif
-      }
-      if constexpr (MASKED) {
-        if (!fmask) pv = ((bits_cur >> (16 * mt + e)) & 1u) ? pv : 0.f;
       }
       return pv;
     };
@@ -609,9 +633,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   float sc0, sc1, mx_cur;
   qk(0, s_cur);
   tile_scales(0, sc0, sc1);
-  bits_cur = allow_bits(0);
-  if (fmask) { to_float_logits(0, bits_cur, s_cur, sc0, sc1); mx_cur = row_max_f(s_cur); }
-  else { mask_scores(bits_cur, s_cur); mx_cur = row_max(s_cur, sc0, sc1); }
+  mask_limit(0, s_cur);
+  mx_cur = row_max(s_cur, sc0, sc1);
 
   // fast loop, unrolled by two so that S(j) / S(j+1) swap roles without register copies
   float4 kk_nxt = load_kscales(min(1, ntiles - 1));
@@ -654,7 +677,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       };
       auto s_step = [&](const int i, const v4i a) __attribute__((always_inline)) {
         const int mt = i / KS, ks = i % KS;
-        sb[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : sb[mt], 0, 0, 0);
+        sb[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], sb[mt], 0, 0, 0);
       };
       auto v_frag8 = [&](const int dt) __attribute__((always_inline)) -> v8i {
         const char* base = vb + dt * 32 * 64;
@@ -748,7 +771,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       };
       auto s_step = [&](const int i, const v4i a) __attribute__((always_inline)) {
         const int mt = i / KS, ks = i % KS;
-        sb[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], ks == 0 ? bias : sb[mt], 0, 0, 0);
+        sb[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], sb[mt], 0, 0, 0);
       };
       float pp[8];  // unrounded p of the quarter in flight (row-sum operands)
       auto p_pair = [&](const int q, const int pr, v8h& pf) __attribute__((always_inline)) {
@@ -840,7 +863,6 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
     fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
-  if (j > 0 && j < wave_tiles) bits_cur = allow_bits(j);  // first generic tile after the fast loop (its max is already in)
   for (; j < wave_tiles; ++j) {
     maybe_rescale(mx_cur);
     if (j + 2 < ntiles) dma_k(j + 2, j & 1);
@@ -849,12 +871,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     if (has_next) {
       tile_scales(j + 1, nsc0, nsc1);
       qk((j + 1) & 1, s_nxt);
-      bits_nxt = allow_bits(j + 1);
-      if (fmask) to_float_logits(j + 1, bits_nxt, s_nxt, nsc0, nsc1); else mask_scores(bits_nxt, s_nxt);
+      mask_limit(j + 1, s_nxt);
     }
     softmax_pv(j, j & 1, s_cur, sc0, sc1, std::true_type{});
-    if (has_next) mx_cur = fmask ? row_max_f(s_nxt) : row_max(s_nxt, nsc0, nsc1);
-    bits_cur = bits_nxt;
+    if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
     if (j + 1 < ntiles) store_v((j + 1) & 1);
     dma_wait_all();
     __syncthreads();

@@ -20,9 +20,13 @@ namespace sage {
 
 // ---- MFMAs with operands pinned to register classes (C and D of an MFMA share one class: ACC_CD)
 // S^T(first k-step) = K.Q^T + bias: D, C (bias), A (K fragment) in VGPRs, B (Q fragment) in AGPRs
+// The accumulator is initialised IN PLACE (C = D): a C operand in a temporary tuple would be dead to hipcc as soon as
+// the statement is issued and could be overwritten while the MFMA still reads it (see attn_i8_kernel, mfma_s_first).
+// s_nop 1: the moves that write the bias are VALU results feeding an MFMA source.
 __device__ __forceinline__ void mfma_s_first(v16i& d, const v4i& a, const v4i& b, const v16i& c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+  d = c;
+  asm("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
 #endif
 }
 __device__ __forceinline__ void mfma_s_acc(v16i& d, const v4i& a, const v4i& b) {

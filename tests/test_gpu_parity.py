@@ -247,6 +247,41 @@ def test_full_size_properties(sa):
         assert (o8.float() - 1).abs().max() < 0.08  # e4m3 P: the fp32 normaliser is not the sum of the rounded P
 
 
+@pytest.mark.parametrize("cfg", [
+    # (B, H, N, D, causal, pv, w64)
+    (4, 32, 2048, 64, True, "fp16", False),   # three waves per SIMD, bias tuple not resident: the configuration that
+    (4, 32, 2048, 64, True, "fp8", False),    # once corrupted the C operand of the first S MFMA (see sage_attn.hip)
+    (4, 32, 2048, 64, False, "fp8", False),
+    (2, 16, 4096, 128, True, "fp16", False),
+    (2, 16, 4096, 128, True, "fp8", False),
+    (2, 16, 2048, 128, True, "fp16", True),   # opt-in 64-rows-per-wave kernel (asm MFMAs)
+])
+def test_run_to_run_determinism(sa, cfg):
+    """The operator is a pure function of its inputs: 40 launches on the same tensors, with the whole chip busy (so that
+    waves queue on the matrix pipe), must give bit-identical outputs and LSE.  Guards the register-reuse hazard class:
+    an MFMA source operand that the compiler may overwrite while the instruction is still in flight."""
+    from sageattention_amd import _lib as L
+    B, H, N, D, causal, pv, w64 = cfg
+    torch.manual_seed(23)
+    q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    lib = L.lib()
+    keep = sa.core.FUSE_Q_QUANT
+    try:
+        if w64:
+            assert lib.sage_set_tuning(1, 1) == 0
+            sa.core.FUSE_Q_QUANT = False
+        o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
+        for _ in range(40):
+            o, l = fn(q, k, v, is_causal=causal, return_lse=True)
+            assert torch.equal(o, o0) and torch.equal(l, l0)
+    finally:
+        sa.core.FUSE_Q_QUANT = keep
+        lib.sage_set_tuning(1, 0)
+
+
 def test_full_size_c4_fp8_causal_properties(sa):
     """BASELINE configs[3] = (4,32,16384,128), INT8 QK^T + FP8 PV, causal, at full size, through properties that do
     not need an O(N^2) reference for the whole tensor: (1) V = 1 => O = 1; (2) causality: with K smoothing off, the
