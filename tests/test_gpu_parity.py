@@ -282,6 +282,31 @@ def test_run_to_run_determinism(sa, cfg):
         lib.sage_set_tuning(1, 0)
 
 
+@pytest.mark.parametrize("cfg", [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (2, 32, 4096, 128, True, "fp16"),
+                                 (2, 32, 4096, 128, False, "fp8"), (4, 32, 2048, 64, False, "fp16")])
+def test_workgroup_geometry_does_not_change_results(sa, cfg):
+    """A wave computes its 32 query rows from the same tiles in the same order whatever the workgroup size, so the
+    4-wave and the 8-wave builds of a kernel must agree bit for bit over the WHOLE output -- a cross-check between two
+    differently scheduled instantiations (registers, occupancy, barriers) that needs no reference."""
+    from sageattention_amd import _lib as L
+    B, H, N, D, causal, pv = cfg
+    torch.manual_seed(29)
+    q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    lib = L.lib()
+    outs = []
+    try:
+        for nw in (4, 8):
+            assert lib.sage_set_tuning(0, nw) == 0
+            outs.append(fn(q, k, v, is_causal=causal, return_lse=True))
+    finally:
+        lib.sage_set_tuning(0, 0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_full_size_c4_fp8_causal_properties(sa):
     """BASELINE configs[3] = (4,32,16384,128), INT8 QK^T + FP8 PV, causal, at full size, through properties that do
     not need an O(N^2) reference for the whole tensor: (1) V = 1 => O = 1; (2) causality: with K smoothing off, the
