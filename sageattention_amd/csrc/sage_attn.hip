@@ -593,7 +593,11 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   int n_plain = wave_tiles;
   if (N_ & 63) n_plain = min(n_plain, N_ >> 6);
   if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
+#ifdef SAGE_ABL_ALLGENERIC
+  const int n_fast = 0;  // cross-check build: every tile through the generic body (results must not change by one bit)
+#else
   const int n_fast = (CAN_MASK && p.mask) ? 0 : max(0, min(n_plain - 1, wave_tiles - 1));  // attn_mask: all tiles generic
+#endif
 
 #ifdef SAGE_EXP_PRIO
   // experiment: static priority for the second-dispatched half of the workgroup (MI355X guide, two waves per SIMD item 4)
