@@ -56,3 +56,28 @@ def test_compiles_as_one_graph(pv):
     oe, le = entry(q, k, v, return_lse=True)
     assert torch.equal(oc, oe + 1.0)
     assert torch.equal(lc, le)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pv", ["fp16", "fp8"])
+def test_operator_captures_into_a_hip_graph(pv):
+    """Every launch goes to the caller's current stream and nothing synchronises or allocates outside the caching
+    allocator: the whole operator (K mean, quantizers, attention, LSE fix) records into a HIP graph and replays with
+    bit-identical results on new input values."""
+    import sageattention_amd as sa
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(2, 4, 384, 128, dtype=torch.float16, device="cuda") for _ in range(3))
+    for _ in range(2):
+        fn(q, k, v, is_causal=True, return_lse=True)   # warm up: module load, function attributes
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o_g, l_g = fn(q, k, v, is_causal=True, return_lse=True)
+    for seed in (2, 3):
+        torch.manual_seed(seed)
+        q.copy_(torch.randn_like(q)); k.copy_(torch.randn_like(k)); v.copy_(torch.randn_like(v))
+        g.replay()
+        torch.cuda.synchronize()
+        o_e, l_e = fn(q, k, v, is_causal=True, return_lse=True)
+        assert torch.equal(o_g, o_e) and torch.equal(l_g, l_e)
