@@ -10,6 +10,8 @@ import ctypes
 import warnings
 from typing import Any, Optional
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -298,12 +300,34 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout="HND", is_causal=Fa
                                         smooth_k=smooth_k, smooth_v=False, return_lse=return_lse)
 
 
+def dispatch_pv(q: torch.Tensor, k: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False) -> str:
+    """"fp8" or "fp16": the P.V precision ``sageattn`` uses for these shapes (see its docstring)."""
+    choice = os.environ.get("SAGEATTN_DISPATCH", "auto")
+    if choice not in ("auto", "fp8", "fp16"):
+        raise ValueError(f"SAGEATTN_DISPATCH must be auto, fp8 or fp16, got {choice}")
+    if choice != "auto":
+        return choice
+    if tensor_layout not in ("HND", "NHD"):
+        raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    n_kv = k.size(2) if tensor_layout == "HND" else k.size(1)
+    keys_per_row = n_kv // 2 if is_causal else n_kv
+    return "fp8" if keys_per_row >= (4096 if q.size(-1) <= 64 else 2048) else "fp16"
+
+
 def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
              sm_scale: Optional[float] = None, return_lse: bool = False, **kwargs: Any):
-    """Drop-in for ``F.scaled_dot_product_attention`` (reference core.py:80-144).  Same dispatch as the fork ships
-    (core.py:144): the INT8-QK / FP8-PV path with fp32 accumulation -- on gfx950 the MX-scaled FP8 MFMA makes it the
-    fastest variant (upstream picks its FP8 kernels on every FP8-capable architecture too, core.py:151-156).  Use
-    ``sageattn_qk_int8_pv_fp16_cuda`` for the FP16-PV accuracy level."""
+    """Drop-in for ``F.scaled_dot_product_attention`` (reference core.py:80-144: "automatically selects the optimal
+    kernel").  The fork dispatches to the INT8-QK / FP8-PV path with fp32 accumulation (core.py:144), and upstream picks
+    its FP8 kernels on every FP8-capable architecture (core.py:151-156): on gfx950 the MX-scaled FP8 MFMA makes that the
+    fastest variant from a few thousand keys upwards.  Below that the per-channel V quantizer (two more launches and
+    two passes over V) costs more than the FP8 MFMA saves, so short sequences take the FP16-PV operator, which is also
+    the more accurate of the two; the crossover was measured end to end (profiles/r01c_sweep_end_to_end.md):
+    keys per query row >= 4096 at head_dim <= 64, >= 2048 above (a causal row sees half the keys on average).
+    ``SAGEATTN_DISPATCH=fp8|fp16`` pins the choice; the two operators are also exported by name."""
+    choice = dispatch_pv(q, k, tensor_layout, is_causal)
+    if choice == "fp16":
+        return sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal,
+                                             sm_scale=sm_scale, return_lse=return_lse, pv_accum_dtype="fp32")
     return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
                                         return_lse=return_lse, pv_accum_dtype="fp32")
 

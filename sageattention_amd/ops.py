@@ -56,11 +56,14 @@ def _(q, k, v, tensor_layout, is_causal, sm_scale, pv, qk_quant_gran):
 
 def sageattn_compilable(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND",
                         is_causal: bool = False, sm_scale: Optional[float] = None, return_lse: bool = False,
-                        pv: str = "fp8", qk_quant_gran: str = "per_thread", **kwargs: Any):
-    """``sageattn`` (core.py:80-144) as a traceable custom op.  Defaults follow the dispatcher of the package
-    (``sageattn`` -> INT8 QK^T + FP8 PV, per_thread); unknown keyword arguments are accepted and ignored like there."""
+                        pv: str = "auto", qk_quant_gran: str = "per_thread", **kwargs: Any):
+    """``sageattn`` (core.py:80-144) as a traceable custom op.  ``pv="auto"`` follows the dispatcher of the package
+    (``core.dispatch_pv``: FP8 PV from a few thousand keys per row upwards, FP16 PV below; per_thread scales); unknown
+    keyword arguments are accepted and ignored like there."""
     if tensor_layout not in ("HND", "NHD"):
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    if pv == "auto":
+        pv = core.dispatch_pv(q, k, tensor_layout, bool(is_causal))
     if sm_scale is None:
         sm_scale = q.size(-1) ** -0.5
     if return_lse:

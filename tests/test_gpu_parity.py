@@ -307,6 +307,27 @@ def test_workgroup_geometry_does_not_change_results(sa, cfg):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def test_sageattn_dispatch_rule(sa, monkeypatch):
+    """``sageattn`` picks FP8 PV from a few thousand keys per query row upwards and FP16 PV below (measured crossover,
+    profiles/r01c_sweep_end_to_end.md); SAGEATTN_DISPATCH pins it.  Checked through bit-equality with the named
+    operators."""
+    torch.manual_seed(3)
+    for (N, D, causal, want) in [(1024, 128, False, "fp16"), (2048, 128, False, "fp8"), (2048, 128, True, "fp16"),
+                                 (2048, 64, False, "fp16"), (4096, 64, False, "fp8")]:
+        q = torch.randn(1, 2, N, D, dtype=torch.float16, device="cuda")
+        k = torch.randn(1, 2, N, D, dtype=torch.float16, device="cuda")
+        v = torch.randn(1, 2, N, D, dtype=torch.float16, device="cuda")
+        assert sa.core.dispatch_pv(q, k, "HND", causal) == want
+        named = sa.sageattn_qk_int8_pv_fp8_cuda if want == "fp8" else sa.sageattn_qk_int8_pv_fp16_cuda
+        assert torch.equal(sa.sageattn(q, k, v, is_causal=causal), named(q, k, v, is_causal=causal))
+    monkeypatch.setenv("SAGEATTN_DISPATCH", "fp8")
+    assert torch.equal(sa.sageattn(q[:, :, :256], k[:, :, :256], v[:, :, :256]),
+                       sa.sageattn_qk_int8_pv_fp8_cuda(q[:, :, :256], k[:, :, :256], v[:, :, :256]))
+    monkeypatch.setenv("SAGEATTN_DISPATCH", "bogus")
+    with pytest.raises(ValueError):
+        sa.sageattn(q, k, v)
+
+
 def test_full_size_c4_fp8_causal_properties(sa):
     """BASELINE configs[3] = (4,32,16384,128), INT8 QK^T + FP8 PV, causal, at full size, through properties that do
     not need an O(N^2) reference for the whole tensor: (1) V = 1 => O = 1; (2) causality: with K smoothing off, the
