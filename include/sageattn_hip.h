@@ -234,6 +234,16 @@ int sage_attn_qk_int8_pv_f16_varlen(const sage_tensor* q8, const sage_tensor* k8
 int sage_merge_attn_states(float* o_acc, float* lse_acc, const void* o_blk, int o_dtype,
                            const float* lse_blk, int64_t rows, int D, sage_stream_t stream);
 
+/* Multi-way form: (o_out, lse_out) = merge of `count` block results (1 <= count <= SAGE_MERGE_MAX) in one pass,
+ *   lse = log(sum_i exp(lse_i));  o = sum_i o_i * exp(lse_i - lse)   (blocks with lse_i = -inf weigh 0).
+ * o_blks[i]: fp16/bf16 [rows, D] contiguous (o_dtype), lse_blks[i]: fp32 [rows] natural log; HOST arrays of
+ * device pointers.  o_out: [rows, D] in o_dtype; lse_out: fp32 [rows] or NULL.  A ring step over P shards otherwise
+ * passes the fp32 accumulator through HBM P times. */
+#define SAGE_MERGE_MAX 16
+int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* lse_blks, int count,
+                                 int o_dtype, void* o_out, float* lse_out, int64_t rows, int D,
+                                 sage_stream_t stream);
+
 /* lse_out[i] = lse2[i]/log2(e) + (corr ? corr[i]*sm_scale : 0)   (core.py:651), n elements. */
 int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out,
                     int64_t n, sage_stream_t stream);

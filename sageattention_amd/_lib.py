@@ -55,6 +55,7 @@ SIGNATURES = {
                                                 ctypes.POINTER(c_int64), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "sage_merge_attn_states": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    "sage_merge_attn_states_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sage_finish_lse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sage_set_tuning": (c_int, [c_int, c_int]),
 }

@@ -33,6 +33,44 @@ __global__ __launch_bounds__(256) void merge_states_kernel(float* __restrict__ o
   if (c == 0) lse_acc[row] = lse;
 }
 
+// Multi-way merge: (o, lse) = merge of up to SAGE_MERGE_MAX block results in ONE pass -- a ring step over P shards
+// otherwise reads and writes the fp32 accumulator P times (sage_merge_attn_states per block).
+struct MergeMany {
+  const uint16_t* o[SAGE_MERGE_MAX];
+  const float* lse[SAGE_MERGE_MAX];
+  int count;
+};
+template <bool BF16>
+__global__ __launch_bounds__(256) void merge_many_kernel(const MergeMany m, uint16_t* __restrict__ o_out,
+                                                         float* __restrict__ lse_out, int64_t rows, int D) {
+  const int tpr = D / 8;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = gid / tpr;
+  const int c = (int)(gid % tpr);
+  if (row >= rows) return;
+  float mx = -INFINITY;
+  for (int i = 0; i < m.count; ++i) mx = fmaxf(mx, m.lse[i][row]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float sum = 0.f;
+  for (int i = 0; i < m.count; ++i) {  // fixed order: deterministic
+    const float l = m.lse[i][row];
+    if (l == -INFINITY) continue;       // empty block (e.g. fully masked): weight 0, its o may be anything
+    const float w = __expf(l - mx);
+    sum += w;
+    float f[8];
+    unpack8<BF16>(*reinterpret_cast<const uint4*>(m.o[i] + row * D + c * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j] * w;
+  }
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    w[j] = (uint32_t)f32_to_elem_bits<BF16>(acc[2 * j] * inv) | ((uint32_t)f32_to_elem_bits<BF16>(acc[2 * j + 1] * inv) << 16);
+  *reinterpret_cast<uint4*>(o_out + row * D + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  if (c == 0 && lse_out) lse_out[row] = sum > 0.f ? mx + __logf(sum) : -INFINITY;
+}
+
 __global__ __launch_bounds__(256) void finish_lse_kernel(const float* __restrict__ lse2, const float* __restrict__ corr,
                                                          float sm_scale, float* __restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -71,6 +109,29 @@ extern "C" int sage_merge_attn_states(float* o_acc, float* lse_acc, const void* 
     hipLaunchKernelGGL((merge_states_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, o_acc, lse_acc, (const uint16_t*)o_blk, lse_blk, rows, D);
   else
     hipLaunchKernelGGL((merge_states_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, o_acc, lse_acc, (const uint16_t*)o_blk, lse_blk, rows, D);
+  return launch_status();
+}
+
+extern "C" int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* lse_blks, int count, int o_dtype,
+                                           void* o_out, float* lse_out, int64_t rows, int D, sage_stream_t stream) {
+  if (!o_blks || !lse_blks || !o_out || count <= 0 || count > SAGE_MERGE_MAX || rows <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  MergeMany m;
+  m.count = count;
+  for (int i = 0; i < count; ++i) {
+    if (!o_blks[i] || !lse_blks[i] || !aligned16(o_blks[i])) return SAGE_ERR_INVALID_ARGUMENT;
+    m.o[i] = (const uint16_t*)o_blks[i];
+    m.lse[i] = lse_blks[i];
+  }
+  for (int i = count; i < SAGE_MERGE_MAX; ++i) { m.o[i] = nullptr; m.lse[i] = nullptr; }
+  if (!aligned16(o_out)) return SAGE_ERR_INVALID_ARGUMENT;
+  const int64_t threads = rows * (D / 8);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (o_dtype == SAGE_BF16)
+    hipLaunchKernelGGL((merge_many_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D);
+  else
+    hipLaunchKernelGGL((merge_many_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D);
   return launch_status();
 }
 

@@ -8,8 +8,8 @@ quantizes its OWN shard once (INT8 K with its local smoothing mean km_r, FP16 or
 km_r and the scales is one contiguous byte buffer that travels around the ring with one send/recv pair per step,
 double buffered, while the fused attention kernel runs on the shard that is already local.  Each step yields
 (o_s, lse_s) for KV shard s, where lse_s is the natural-log LSE of the true logits (the smooth-K correction
-(q.km_s)*sm_scale is applied per shard, core.py:651), and the partial results are merged with
-    lse = logaddexp(lse_a, lse_b);  o = o_a*exp(lse_a-lse) + o_b*exp(lse_b-lse).
+(q.km_s)*sm_scale is applied per shard, core.py:651), and the partial results are merged ONCE at the end of the step with
+    lse = log(sum_s exp(lse_s));  o = sum_s o_s*exp(lse_s-lse)     (sage_merge_attn_states_multi).
 Causal: shards are contiguous in the sequence, so a shard from a later rank is skipped, the rank's own shard is
 causal, earlier shards are full attention.  Per step and rank the ring moves Hk*n*D bytes of K + 2*Hk*n*D (fp16 V)
 or Hk*n*D (fp8 V) over one xGMI link.
@@ -123,17 +123,24 @@ class HipRingBackend:
                                         L.stream_ptr(q.device)), "sage_finish_lse")
         return o, lse
 
-    def new_state(self, q):
-        B, H, M, D = q.shape
-        return (torch.zeros((B, H, M, D), dtype=torch.float32, device=q.device),
-                torch.full((B, H, M), float("-inf"), dtype=torch.float32, device=q.device))
+    MERGE_MAX = 16  # SAGE_MERGE_MAX
 
-    def merge(self, state, o_blk, lse_blk):
-        o_acc, lse_acc = state
-        L.check(L.lib().sage_merge_attn_states(o_acc.data_ptr(), lse_acc.data_ptr(), o_blk.data_ptr(),
-                                               L.dtype_code(o_blk.dtype), lse_blk.data_ptr(), lse_acc.numel(),
-                                               o_acc.shape[-1], L.stream_ptr(o_acc.device)), "sage_merge_attn_states")
-        return state
+    def merge_all(self, blocks):
+        """(o, lse) of the union of the KV shards from the per-shard results [(o_blk, lse_blk), ...]: one multi-way
+        merge pass (sage_merge_attn_states_multi) instead of one fp32 accumulator round trip per block."""
+        import ctypes
+        while len(blocks) > 1:
+            grp, rest = blocks[:self.MERGE_MAX], blocks[self.MERGE_MAX:]
+            o0 = grp[0][0]
+            o = torch.empty(o0.shape, dtype=o0.dtype, device=o0.device)
+            lse = torch.empty(grp[0][1].shape, dtype=torch.float32, device=o0.device)
+            op = (ctypes.c_void_p * len(grp))(*[b[0].data_ptr() for b in grp])
+            lp = (ctypes.c_void_p * len(grp))(*[b[1].data_ptr() for b in grp])
+            L.check(L.lib().sage_merge_attn_states_multi(op, lp, len(grp), L.dtype_code(o0.dtype), o.data_ptr(), lse.data_ptr(),
+                                                         lse.numel(), o0.shape[-1], L.stream_ptr(o0.device)),
+                    "sage_merge_attn_states_multi")
+            blocks = [(o, lse)] + rest
+        return blocks[0]
 
 
 def _pack(parts):
@@ -197,25 +204,23 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
 
     qstate = be.prepare_q(q, sm_scale)
     cur_buf, cur = _pack(be.prepare_kv(k, v))
-    state = be.new_state(q)
+    blocks = []  # per-shard (o, lse), merged once at the end
 
     n_loc = q.size(2)
     half = n_loc // 2
-    if zigzag:  # separate (contiguous) accumulators for the two half-blocks of query rows
+    if zigzag:  # separate result lists for the two half-blocks of query rows
         q_part = {"lo": be.slice_q(qstate, 0, half), "hi": be.slice_q(qstate, half, n_loc)}
-        zstate = {"lo": be.new_state(q[:, :, :half]), "hi": be.new_state(q[:, :, half:])}
+        zblocks = {"lo": [], "hi": []}
         kv_rng = {"lo": (0, half), "hi": (half, n_loc), "all": (0, n_loc)}
 
     def skips(src, dst):  # rank dst never touches the shard of rank src
         return is_causal and not zigzag and src > dst
 
     def consume(views, src):
-        nonlocal state
         if skips(src, rank):
             return
         if not zigzag:
-            o_blk, lse_blk = be.block_attn(qstate, views, is_causal and src == rank)
-            state = be.merge(state, o_blk, lse_blk)
+            blocks.append(be.block_attn(qstate, views, is_causal and src == rank))
             return
         if src < rank:
             pairs = (("lo", "lo", False), ("hi", "lo", False))
@@ -225,8 +230,7 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
             pairs = (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True))
         for qa, kb, diag in pairs:
             kv = views if kb == "all" else be.slice_kv(views, *kv_rng[kb])
-            o_blk, lse_blk = be.block_attn(q_part[qa], kv, diag)
-            zstate[qa] = be.merge(zstate[qa], o_blk, lse_blk)
+            zblocks[qa].append(be.block_attn(q_part[qa], kv, diag))
 
     if schedule == "ring" or world == 1:
         nxt_buf = torch.empty_like(cur_buf) if world > 1 else None
@@ -260,11 +264,10 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
             consume(_views_like(rbufs[src], cur), src)
 
     if zigzag:
-        o_acc = torch.cat([zstate["lo"][0], zstate["hi"][0]], dim=2)
-        lse = torch.cat([zstate["lo"][1], zstate["hi"][1]], dim=2)
+        (o_lo, l_lo), (o_hi, l_hi) = be.merge_all(zblocks["lo"]), be.merge_all(zblocks["hi"])
+        o, lse = torch.cat([o_lo, o_hi], dim=2), torch.cat([l_lo, l_hi], dim=2)
     else:
-        o_acc, lse = state
-    o = o_acc.to(q.dtype)
+        o, lse = be.merge_all(blocks)
     if tensor_layout == "NHD":
         o = o.transpose(1, 2)
     return (o, lse) if return_lse else o

@@ -58,10 +58,9 @@ class OracleRingBackend:
         corr = O.lse_correction(q, kv["km"], "HND")
         return o, lse2 / O.LOG2E + corr * sm
 
-    def new_state(self, q):
-        B, H, M, D = q.shape
-        return torch.zeros(B, H, M, D), torch.full((B, H, M), float("-inf"))
-
-    def merge(self, state, o_blk, lse_blk):
-        o, l = O.merge_attn_states(state[0], state[1], o_blk, lse_blk)
-        return o, l
+    def merge_all(self, blocks):
+        lses = torch.stack([b[1] for b in blocks])                       # [P,B,H,M]
+        lse = torch.logsumexp(lses, dim=0)
+        w = torch.exp(lses - lse).nan_to_num(0.0)                        # blocks with lse = -inf weigh 0
+        o = sum(b[0].float() * w[i].unsqueeze(-1) for i, b in enumerate(blocks))
+        return o.to(blocks[0][0].dtype), lse

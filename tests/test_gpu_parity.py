@@ -360,6 +360,39 @@ def test_full_size_c4_fp8_causal_properties(sa):
     assert (lse[sl].cpu() - ol).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize("count,dt,D", [(1, torch.float16, 64), (3, torch.float16, 128), (8, torch.bfloat16, 128), (16, torch.float16, 64)])
+def test_multiway_merge_vs_torch(sa, count, dt, D):
+    """sage_merge_attn_states_multi: o = sum_i o_i exp(lse_i - lse), lse = logsumexp_i lse_i, in one pass; blocks with
+    lse = -inf (nothing attended) weigh zero whatever their o holds; rows where every block is empty give (0, -inf)."""
+    import ctypes
+    from sageattention_amd import _lib as L
+    torch.manual_seed(count)
+    rows = 1000
+    os_ = [torch.randn(rows, D, device="cuda").to(dt) for _ in range(count)]
+    ls = [torch.randn(rows, device="cuda") * 3 for _ in range(count)]
+    if count > 1:
+        ls[1][::7] = float("-inf")
+        os_[1][::7] = float("nan")          # must not leak: weight 0
+        for l in ls:
+            l[5] = float("-inf")            # a row nobody attended
+    o = torch.empty(rows, D, dtype=dt, device="cuda")
+    lse = torch.empty(rows, dtype=torch.float32, device="cuda")
+    op = (ctypes.c_void_p * count)(*[t.data_ptr() for t in os_])
+    lp = (ctypes.c_void_p * count)(*[t.data_ptr() for t in ls])
+    L.check(L.lib().sage_merge_attn_states_multi(op, lp, count, L.dtype_code(dt), o.data_ptr(), lse.data_ptr(), rows, D,
+                                                 L.stream_ptr(o.device)), "merge")
+    lst = torch.stack(ls)
+    ref_l = torch.logsumexp(lst, dim=0)
+    w = torch.exp(lst - ref_l).nan_to_num(0.0)
+    ref_o = sum(torch.where(w[i].unsqueeze(-1) > 0, os_[i].float() * w[i].unsqueeze(-1), torch.zeros(1, device="cuda"))
+                for i in range(count))
+    assert torch.equal(torch.isinf(lse), torch.isinf(ref_l))
+    fin = ~torch.isinf(ref_l)
+    assert (lse[fin] - ref_l[fin]).abs().max() < 1e-5
+    assert (o.float() - ref_o).abs().max() < (2e-3 if dt == torch.float16 else 2e-2)
+    assert L.lib().sage_merge_attn_states_multi(op, lp, 17, 0, o.data_ptr(), lse.data_ptr(), rows, D, None) == -1
+
+
 @pytest.mark.parametrize("pv", ["fp16", "fp8"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_ring_steps_on_one_gpu(sa, pv, causal):
@@ -381,14 +414,14 @@ def test_ring_steps_on_one_gpu(sa, pv, causal):
     for r in range(P):
         qr = q[:, :, r * n:(r + 1) * n]
         qs = be.prepare_q(qr, D ** -0.5)
-        st = be.new_state(qr)
+        blks = []
         for step in range(P):
             src = (r - step) % P
             if causal and src > r:
                 continue
-            ob, lb = be.block_attn(qs, shards[src], causal and src == r)
-            st = be.merge(st, ob, lb)
-        outs.append(st[0]); lses.append(st[1])
+            blks.append(be.block_attn(qs, shards[src], causal and src == r))
+        st = be.merge_all(blks)
+        outs.append(st[0].float()); lses.append(st[1])
     o = torch.cat(outs, dim=2).cpu()
     lse = torch.cat(lses, dim=2).cpu()
     ref, ref_lse = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=causal, return_lse=True)
@@ -464,17 +497,17 @@ def test_zigzag_half_blocks_on_one_gpu(sa, pv, gran):
         ql = zigzag_split(q, P, r)
         qs = be.prepare_q(ql, D ** -0.5)
         qp = {"lo": be.slice_q(qs, 0, h), "hi": be.slice_q(qs, h, n)}
-        st = {"lo": be.new_state(ql[:, :, :h]), "hi": be.new_state(ql[:, :, h:])}
+        st = {"lo": [], "hi": []}
         for step in range(P):
             s = (r - step) % P
             pairs = ((("lo", "lo", False), ("hi", "lo", False)) if s < r else (("hi", "all", False),) if s > r
                      else (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True)))
             for qa, kb, diag in pairs:
                 kv = shards[s] if kb == "all" else be.slice_kv(shards[s], *rng[kb])
-                ob, lb = be.block_attn(qp[qa], kv, diag)
-                st[qa] = be.merge(st[qa], ob, lb)
-        outs.append(torch.cat([st["lo"][0], st["hi"][0]], dim=2))
-        lses.append(torch.cat([st["lo"][1], st["hi"][1]], dim=2))
+                st[qa].append(be.block_attn(qp[qa], kv, diag))
+        mlo, mhi = be.merge_all(st["lo"]), be.merge_all(st["hi"])
+        outs.append(torch.cat([mlo[0], mhi[0]], dim=2).float())
+        lses.append(torch.cat([mlo[1], mhi[1]], dim=2))
     o = zigzag_merge(outs).cpu()
     lse = zigzag_merge(lses).cpu()
     ref, ref_lse = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=True, return_lse=True)

@@ -80,13 +80,13 @@ def test_ring_matches_full_attention(tmp_path, world, causal, pv, layout, schedu
     shards = [be.prepare_kv(k[:, :, r * n:(r + 1) * n], v[:, :, r * n:(r + 1) * n]) for r in range(world)]
     for r in range(world):
         qs = be.prepare_q(q[:, :, r * n:(r + 1) * n], D ** -0.5)
-        st = be.new_state(q[:, :, r * n:(r + 1) * n])
+        blks = []
         for step in range(world):
             src = (r - step) % world
             if causal and src > r:
                 continue
-            ob, lb = be.block_attn(qs, shards[src], causal and src == r)
-            st = be.merge(st, ob, lb)
+            blks.append(be.block_attn(qs, shards[src], causal and src == r))
+        st = be.merge_all(blks)
         assert torch.equal(st[0].to(torch.float16), outs[r]["o"]), f"rank {r} output differs from the serial ring"
         assert torch.equal(st[1], outs[r]["lse"])
 
@@ -121,7 +121,7 @@ def test_zigzag_causal_ring(tmp_path, world, pv, layout, schedule):
         ql = zigzag_split(q, world, r)
         qs = be.prepare_q(ql, D ** -0.5)
         qp = {"lo": be.slice_q(qs, 0, h), "hi": be.slice_q(qs, h, n)}
-        st = {"lo": be.new_state(ql[:, :, :h]), "hi": be.new_state(ql[:, :, h:])}
+        st = {"lo": [], "hi": []}
         rng = {"lo": (0, h), "hi": (h, n)}
         blocks = 0.0
         for step in range(world):
@@ -130,11 +130,11 @@ def test_zigzag_causal_ring(tmp_path, world, pv, layout, schedule):
                      else (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True)))
             for qa, kb, diag in pairs:
                 kv = shards[s] if kb == "all" else be.slice_kv(shards[s], *rng[kb])
-                ob, lb = be.block_attn(qp[qa], kv, diag)
-                st[qa] = be.merge(st[qa], ob, lb)
+                st[qa].append(be.block_attn(qp[qa], kv, diag))
                 blocks += (2.0 if kb == "all" else 1.0) * (0.5 if diag else 1.0)
         work.append(blocks)
-        o_ser = torch.cat([st["lo"][0], st["hi"][0]], dim=2).to(torch.float16)
+        mlo, mhi = be.merge_all(st["lo"]), be.merge_all(st["hi"])
+        o_ser = torch.cat([mlo[0], mhi[0]], dim=2).to(torch.float16)
         assert torch.equal(o_ser, outs[r]["o"]), f"rank {r} output differs from the serial replay"
-        assert torch.equal(torch.cat([st["lo"][1], st["hi"][1]], dim=2), outs[r]["lse"])
+        assert torch.equal(torch.cat([mlo[1], mhi[1]], dim=2), outs[r]["lse"])
     assert len(set(work)) == 1, f"zigzag must balance the half-block products across ranks, got {work}"
