@@ -106,8 +106,18 @@ class HipRingBackend:
             out["vs"] = kv["vs"]
         return out
 
-    def block_attn(self, qstate, kv, causal: bool):
-        """(o_blk [B,H,M,D] in q's dtype, lse [B,H,M] natural log of the true logits) for one KV shard."""
+    def lse_corrections(self, qstate, kvs):
+        """Smooth-K corrections (q . km_s) for several shards in ONE pass over q: fp32 [P,B,H,M]."""
+        q = qstate["q"]
+        kms = torch.stack([kv["km"] for kv in kvs])                       # [P,B,Hk,D]
+        g = q.shape[1] // kms.shape[2]
+        if g > 1:
+            kms = kms.repeat_interleave(g, dim=2)
+        return torch.einsum("bhmd,pbhd->pbhm", q, kms).float().contiguous()
+
+    def block_attn(self, qstate, kv, causal: bool, corr=None):
+        """(o_blk [B,H,M,D] in q's dtype, lse [B,H,M] natural log of the true logits) for one KV shard.
+        corr: precomputed (q . km_s) [B,H,M] fp32 (lse_corrections), else computed here."""
         q, q8, qs, sm = qstate["q"], qstate["q8"], qstate["qs"], qstate["sm_scale"]
         o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
         if self.pv == "fp16":
@@ -115,9 +125,11 @@ class HipRingBackend:
         else:
             lse2 = _qattn._attn_f8(q8, kv["k8"], kv["v"], o, qs, kv["ks"], kv["vs"], None, 1, int(causal), self.code, sm, 1)
         # smooth-K correction of THIS shard: (q . km_s) * sm_scale   (core.py:613-617, 651)
-        g = q.shape[1] // kv["km"].shape[1]
-        km = kv["km"].repeat_interleave(g, dim=1) if g > 1 else kv["km"]
-        corr = torch.einsum("bhmd,bhd->bhm", q, km).float().contiguous()
+        if corr is None:
+            g = q.shape[1] // kv["km"].shape[1]
+            km = kv["km"].repeat_interleave(g, dim=1) if g > 1 else kv["km"]
+            corr = torch.einsum("bhmd,bhd->bhm", q, km).float()
+        corr = corr.contiguous()
         lse = torch.empty_like(lse2)
         L.check(L.lib().sage_finish_lse(lse2.data_ptr(), corr.data_ptr(), float(sm), lse.data_ptr(), lse2.numel(),
                                         L.stream_ptr(q.device)), "sage_finish_lse")
@@ -216,11 +228,11 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
     def skips(src, dst):  # rank dst never touches the shard of rank src
         return is_causal and not zigzag and src > dst
 
-    def consume(views, src):
+    def consume(views, src, corr=None):
         if skips(src, rank):
             return
         if not zigzag:
-            blocks.append(be.block_attn(qstate, views, is_causal and src == rank))
+            blocks.append(be.block_attn(qstate, views, is_causal and src == rank, **({} if corr is None else {"corr": corr})))
             return
         if src < rank:
             pairs = (("lo", "lo", False), ("hi", "lo", False))
@@ -230,7 +242,8 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
             pairs = (("lo", "lo", True), ("hi", "lo", False), ("hi", "hi", True))
         for qa, kb, diag in pairs:
             kv = views if kb == "all" else be.slice_kv(views, *kv_rng[kb])
-            zblocks[qa].append(be.block_attn(q_part[qa], kv, diag))
+            rows = slice(0, half) if qa == "lo" else slice(half, n_loc)
+            zblocks[qa].append(be.block_attn(q_part[qa], kv, diag, **({} if corr is None else {"corr": corr[:, :, rows]})))
 
     if schedule == "ring" or world == 1:
         nxt_buf = torch.empty_like(cur_buf) if world > 1 else None
@@ -260,8 +273,11 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
         consume(cur, rank)
         for r in reqs:  # RCCL completes the group as a whole; shards are consumed in ring order afterwards
             r.wait()
-        for src in need:
-            consume(_views_like(rbufs[src], cur), src)
+        views = [_views_like(rbufs[src], cur) for src in need]
+        # the smooth-K corrections of all remote shards in one pass over q (backends without the batched form do it per block)
+        corrs = be.lse_corrections(qstate, views) if (views and hasattr(be, "lse_corrections")) else None
+        for i, src in enumerate(need):
+            consume(views[i], src, None if corrs is None else corrs[i])
 
     if zigzag:
         (o_lo, l_lo), (o_hi, l_hi) = be.merge_all(zblocks["lo"]), be.merge_all(zblocks["hi"])
