@@ -6,8 +6,9 @@
 A "step" is one pass of the whole hot path (K mean -> INT8 Q/K quantizers -> fused attention kernel) over one
 batch of synthetic (q,k,v) already resident in HBM.  TFLOPS = 4*B*H*M*N*D / t (/2 causal), the reference's own
 formula (bench/bench_baseline.py:31).  N=1 default workload: C3 = qk_int8_pv_fp16, (B,H,N,D)=(4,32,8192,128), the
-configuration the metric is quoted on.  N>1: ring sequence-parallel attention over RCCL on (1,32,65536,128)
-(BASELINE configs[4]), strong scaling.  Prints ONE JSON line on rank 0.
+configuration the metric is quoted on.  N>1: ring sequence-parallel `sageattn` over RCCL on (1,32,65536,128)
+(BASELINE configs[4]; at 64K keys the dispatcher's choice is the INT8-QK / FP8-PV operator), strong scaling.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,7 +30,7 @@ WORKLOADS = {
     "c2": (4, 32, 2048, 64, False, "fp16"),
     "c3": (4, 32, 8192, 128, False, "fp16"),
     "c4": (4, 32, 16384, 128, True, "fp8"),
-    "ring": (1, 32, 65536, 128, False, "fp16"),
+    "ring": (1, 32, 65536, 128, False, "fp8"),   # configs[4] names `sageattn`: at 64K keys its dispatcher picks the FP8-PV operator
 }
 
 

@@ -300,8 +300,10 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout="HND", is_causal=Fa
                                         smooth_k=smooth_k, smooth_v=False, return_lse=return_lse)
 
 
-def dispatch_pv(q: torch.Tensor, k: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False) -> str:
-    """"fp8" or "fp16": the P.V precision ``sageattn`` uses for these shapes (see its docstring)."""
+def dispatch_pv(q: torch.Tensor, k: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
+                n_kv: Optional[int] = None) -> str:
+    """"fp8" or "fp16": the P.V precision ``sageattn`` uses for these shapes (see its docstring).  ``n_kv`` overrides
+    the key count (sequence-parallel callers pass the length of the WHOLE sequence)."""
     choice = os.environ.get("SAGEATTN_DISPATCH", "auto")
     if choice not in ("auto", "fp8", "fp16"):
         raise ValueError(f"SAGEATTN_DISPATCH must be auto, fp8 or fp16, got {choice}")
@@ -309,7 +311,8 @@ def dispatch_pv(q: torch.Tensor, k: torch.Tensor, tensor_layout: str = "HND", is
         return choice
     if tensor_layout not in ("HND", "NHD"):
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
-    n_kv = k.size(2) if tensor_layout == "HND" else k.size(1)
+    if n_kv is None:
+        n_kv = k.size(2) if tensor_layout == "HND" else k.size(1)
     keys_per_row = n_kv // 2 if is_causal else n_kv
     return "fp8" if keys_per_row >= (4096 if q.size(-1) <= 64 else 2048) else "fp16"
 

@@ -184,7 +184,7 @@ def _views_like(buf, views):
 
 @torch.compiler.disable
 def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
-                  sm_scale: Optional[float] = None, group: Optional[dist.ProcessGroup] = None, pv: str = "fp16",
+                  sm_scale: Optional[float] = None, group: Optional[dist.ProcessGroup] = None, pv: str = "auto",
                   qk_quant_gran: str = "per_thread", return_lse: bool = False, backend: Any = None,
                   schedule: str = "direct", causal_layout: str = "contiguous", **kwargs: Any):
     """SageAttention over a sequence sharded across the ranks of ``group``.  Equal shard lengths; rank r holds rows
@@ -207,9 +207,12 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
         raise ValueError(f"ring_sageattn supports head_dim 64 or 128, got {D}")
     if sm_scale is None:
         sm_scale = D ** -0.5
-    be = backend if backend is not None else HipRingBackend(pv, qk_quant_gran)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if pv == "auto":  # the dispatcher's rule (core.dispatch_pv) on the WHOLE sequence: FP8 PV from a few thousand keys per row
+        from .core import dispatch_pv
+        pv = dispatch_pv(q, k, "HND", is_causal, n_kv=k.size(2) * world)
+    be = backend if backend is not None else HipRingBackend(pv, qk_quant_gran)
 
     def peer(r):  # group rank -> global rank for P2POp
         return dist.get_global_rank(group, r) if (world > 1 and group is not None) else r

@@ -47,7 +47,7 @@ def _head_to_seq(y: torch.Tensor, world: int, group) -> torch.Tensor:
 @torch.compiler.disable
 def ulysses_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND",
                      is_causal: bool = False, sm_scale: Optional[float] = None,
-                     group: Optional[dist.ProcessGroup] = None, pv: str = "fp16", qk_quant_gran: str = "per_thread",
+                     group: Optional[dist.ProcessGroup] = None, pv: str = "auto", qk_quant_gran: str = "per_thread",
                      return_lse: bool = False, attn_fn: Optional[Callable] = None, **kwargs: Any):
     """SageAttention over a sequence sharded across the ranks of ``group`` (rank r holds rows [r*n, (r+1)*n); equal
     shard lengths), parallel over heads.  Same tensor conventions as ``sageattn``; returns this rank's output rows
@@ -56,9 +56,12 @@ def ulysses_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_l
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     elif tensor_layout != "HND":
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if pv == "auto":  # the dispatcher's rule on the whole sequence
+        from .core import dispatch_pv
+        pv = dispatch_pv(q, k, "HND", is_causal, n_kv=k.size(2) * world)
     if pv not in ("fp16", "fp8"):
         raise ValueError(f"Unknown pv: {pv}")
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
     Hq, Hk = q.size(1), k.size(1)
     if Hq % world or Hk % world:
         raise ValueError(f"ulysses_sageattn needs head counts divisible by the group size: Hq={Hq}, Hk={Hk}, P={world}")
