@@ -145,7 +145,9 @@ int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D
  *   core.py:633 `v.to(float16)`), o [B,Hq,M,D] fp16/bf16 (o_dtype).
  *   q_scale / k_scale: fp32 [B,Hq,Gq] / [B,Hk,Gk] with the shapes sage_quant_qk_int8 produces for
  *   (gran, blkq, warpq, blkk=64, warpk=64)  (…sm80.cu:796-805).
- *   sm_scale: logits are multiplied by sm_scale*log2(e) inside the kernel (…sm80.cu:92).
+ *   sm_scale: logits are multiplied by sm_scale*log2(e) inside the kernel (…sm80.cu:92); must be
+ *   positive and finite (SAGE_ERR_INVALID_ARGUMENT otherwise: the integer row max and the masks
+ *   assume a positive dequantisation scale).
  *   logit_mult_is_one != 0: the scales already contain sm_scale*log2e (triton per_block path,
  *   attn_qk_int8_per_block.py:47) and sm_scale is ignored.
  *   v_mean: optional fp32 [B,Hk,D] added to the output rows (fuse_v_mean).

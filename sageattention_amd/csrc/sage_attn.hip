@@ -1003,6 +1003,8 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   if (!t_ok(q8, fusedq ? 8 : 16) || !t_ok(k8, 16) || !t_ok(v, pv_fp8 ? 16 : 8) || !t_ok(o, 4) || !q_scale || !k_scale) return SAGE_ERR_INVALID_ARGUMENT;
   if (pv_fp8 && !v_scale) return SAGE_ERR_INVALID_ARGUMENT;
   if (B <= 0 || Hq <= 0 || Hk <= 0 || M <= 0 || N <= 0 || Hq % Hk != 0) return SAGE_ERR_INVALID_ARGUMENT;
+  // the integer row max and the -inf mask pattern rely on a positive, finite dequantisation scale
+  if (!logit_mult_is_one && !(sm_scale > 0.f && sm_scale < 1.0e30f)) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if ((v_dtype != SAGE_F16 && v_dtype != SAGE_BF16) || (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16)) return SAGE_ERR_INVALID_ARGUMENT;
   if (qk_gran < SAGE_GRAN_PER_BLOCK || qk_gran > SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;

@@ -216,6 +216,15 @@ def test_api_surface_and_errors(sa):
     assert (o.float() - ref).abs().max() < 0.05
 
 
+def test_non_positive_sm_scale_is_rejected(sa):
+    q = torch.randn(1, 2, 128, 64, dtype=torch.float16, device="cuda")
+    for bad in (0.0, -0.125, float("inf"), float("nan")):
+        with pytest.raises(ValueError):
+            sa.sageattn_qk_int8_pv_fp16_cuda(q, q, q, sm_scale=bad)
+        with pytest.raises(ValueError):
+            sa.sageattn_qk_int8_pv_fp8_cuda(q, q, q, sm_scale=bad)
+
+
 def test_full_size_properties(sa):
     """BASELINE full sizes through size-independent properties: (1) V = 1 => O = 1 exactly up to fp16 rounding
     (softmax rows sum to one, normaliser consistent with P); (2) a slice of heads equals the oracle; both at
