@@ -57,16 +57,16 @@ def _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, want_lse_
     grp = Hq // Hk
     if qk_quant_gran == "per_block":  # triton path: sm_scale*log2e folded into Q (quant_per_block.py:84)
         q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_BLOCK, False, 128, 128, sm_scale * 1.44269504, L.ROUND_TRITON,
-                              dot_vec=dot_vec, dot_group=grp)
-        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km)
+                              dot_vec=dot_vec, dot_group=grp, dense_heads=True)
+        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km, dense_heads=True)
     elif qk_quant_gran == "per_warp":
         q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_WARP, False, 128, WARPQ, 1.0, L.ROUND_CUDA,
-                              dot_vec=dot_vec, dot_group=grp)
-        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km)
+                              dot_vec=dot_vec, dot_group=grp, dense_heads=True)
+        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km, dense_heads=True)
     elif qk_quant_gran == "per_thread":
         q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_THREAD, False, 128, WARPQ, 1.0, L.ROUND_TRITON,
-                              dot_vec=dot_vec, dot_group=grp)
-        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km)
+                              dot_vec=dot_vec, dot_group=grp, dense_heads=True)
+        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km, dense_heads=True)
     else:
         raise ValueError(f"Unsupported qk_quant_gran: {qk_quant_gran}")
     return q8, qs, k8, ks, corr
@@ -92,8 +92,8 @@ FUSE_Q_MAX_SEQ = 4096
 def _quant_k(k, km, tensor_layout, qk_quant_gran):
     """K half of core.py:621-624."""
     if qk_quant_gran == "per_warp":
-        return _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km)[:2]
-    return _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km)[:2]
+        return _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km, dense_heads=True)[:2]
+    return _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km, dense_heads=True)[:2]
 
 
 def _fused_attn(q, k8, ks, v, o, km, v_scale, v_mean, tensor_layout, is_causal, qk_quant_gran, warpq, sm_scale, return_lse,

@@ -19,9 +19,16 @@ def _km3(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torch.Tenso
     return km.contiguous()
 
 
-def _quant(x, tensor_layout, gran, is_key, blk, warp, mult, rounding, mean=None, dot_vec=None, dot_group=1):
+def _quant(x, tensor_layout, gran, is_key, blk, warp, mult, rounding, mean=None, dot_vec=None, dot_group=1,
+           dense_heads=False):
+    """dense_heads: for an NHD input, give the int8 result head-major storage ([B,H,N,D] contiguous, returned as its
+    [B,N,H,D] view): it is an internal operand of the attention kernel, which then streams K/Q rows of one head from
+    consecutive lines instead of one line per H*D bytes (the C ABI takes strides per tensor)."""
     B, H, N, D = L.dims(x, tensor_layout)
-    out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    if dense_heads and tensor_layout == "NHD":
+        out = torch.empty((B, H, N, D), dtype=torch.int8, device=x.device).transpose(1, 2)
+    else:
+        out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
     nblk = (N + blk - 1) // blk
     if gran == L.GRAN_PER_BLOCK:
         G = nblk
