@@ -324,7 +324,7 @@ def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
     its FP8 kernels on every FP8-capable architecture (core.py:151-156): on gfx950 the MX-scaled FP8 MFMA makes that the
     fastest variant from a few thousand keys upwards.  Below that the per-channel V quantizer (two more launches and
     two passes over V) costs more than the FP8 MFMA saves, so short sequences take the FP16-PV operator, which is also
-    the more accurate of the two; the crossover was measured end to end (profiles/r01c_sweep_end_to_end.md):
+    the more accurate of the two; the crossover was measured end to end (profiles/r01d_sweep_end_to_end.md):
     keys per query row >= 4096 at head_dim <= 64, >= 2048 above (a causal row sees half the keys on average).
     ``SAGEATTN_DISPATCH=fp8|fp16`` pins the choice; the two operators are also exported by name."""
     choice = dispatch_pv(q, k, tensor_layout, is_causal)

@@ -318,7 +318,7 @@ def test_workgroup_geometry_does_not_change_results(sa, cfg):
 
 def test_sageattn_dispatch_rule(sa, monkeypatch):
     """``sageattn`` picks FP8 PV from a few thousand keys per query row upwards and FP16 PV below (measured crossover,
-    profiles/r01c_sweep_end_to_end.md); SAGEATTN_DISPATCH pins it.  Checked through bit-equality with the named
+    profiles/r01d_sweep_end_to_end.md); SAGEATTN_DISPATCH pins it.  Checked through bit-equality with the named
     operators."""
     torch.manual_seed(3)
     for (N, D, causal, want) in [(1024, 128, False, "fp16"), (2048, 128, False, "fp8"), (2048, 128, True, "fp16"),
