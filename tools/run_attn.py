@@ -10,7 +10,9 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 nw = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False),
-                      "c3c": (4, 32, 8192, 128, True), "c2c": (4, 32, 2048, 64, True)}[wl]
+                      "c3c": (4, 32, 8192, 128, True), "c2c": (4, 32, 2048, 64, True),
+                      "c4": (4, 32, 16384, 128, True)}[wl]
+fp8 = wl == "c4"  # configs[3]: INT8 QK^T + FP8 PV
 L.lib().sage_set_tuning(0, nw)
 torch.manual_seed(0)
 q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
@@ -19,7 +21,12 @@ v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
 km = sa.quant.k_mean(k)
 q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
 o = torch.empty_like(q)
+if fp8:
+    v8, vsc, _ = sa.quant.per_channel_fp8(v, smooth_v=False)
 for _ in range(iters):
-    _qattn._attn_f16(q8, k8, v, o, qs, ks, None, 1, int(causal), 3, D ** -0.5, 0)
+    if fp8:
+        _qattn._attn_f8(q8, k8, v8, o, qs, ks, vsc, None, 1, int(causal), 3, D ** -0.5, 0)
+    else:
+        _qattn._attn_f16(q8, k8, v, o, qs, ks, None, 1, int(causal), 3, D ** -0.5, 0)
 torch.cuda.synchronize()
 print("done", wl, iters)
