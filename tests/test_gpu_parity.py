@@ -577,13 +577,15 @@ def test_fused_q_quantizer_is_bit_identical(sa, golden, gran, pv):
     g, m = golden, golden.meta
     fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
     kw = dict(tensor_layout=m["layout"], is_causal=bool(m["causal"]), qk_quant_gran=gran, return_lse=True, pv_accum_dtype="fp32")
-    assert core.FUSE_Q_QUANT and m["M"] <= core.FUSE_Q_MAX_SEQ
-    o1, l1 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
-    core.FUSE_Q_QUANT = False
+    assert m["M"] <= core.FUSE_Q_MAX_SEQ
+    keep = core.FUSE_Q_QUANT
     try:
+        core.FUSE_Q_QUANT = True    # opt-in path (core.py)
+        o1, l1 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
+        core.FUSE_Q_QUANT = False
         o0, l0 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
     finally:
-        core.FUSE_Q_QUANT = True
+        core.FUSE_Q_QUANT = keep
     torch.cuda.synchronize()
     assert torch.equal(o1, o0), (o1.float() - o0.float()).abs().max()
     assert (l1 - l0).abs().max() < 1e-5 * max(1.0, float(l0.abs().max()))

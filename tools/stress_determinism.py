@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Determinism under perturbed timing: every checked launch is preceded by a different heavy kernel (clock / power /
+cache state as inside the test suite), several configurations."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+if os.environ.get("SAGE_LIB_OVERRIDE"):
+    import sageattention_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["SAGE_LIB_OVERRIDE"])
+import sageattention_amd as sa
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+if len(sys.argv) > 2:  # "nofuse": Q quantizer as a separate kernel
+    sa.core.FUSE_Q_QUANT = sys.argv[2] != "nofuse"
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+torch.manual_seed(23)
+big = [torch.randn(4, 32, 8192, 128, dtype=torch.float16, device="cuda") for _ in range(3)]
+cfgs = [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8"),
+        (2, 16, 4096, 128, True, "fp16"), (2, 16, 4096, 128, True, "fp8"), (4, 32, 2048, 64, False, "fp16")]
+for (B, H, N, D, causal, pv) in (cfgs if only is None else cfgs[only:only + 1]):
+    q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
+    nd, first = 0, None
+    for it in range(runs):
+        if it % 3 == 0:
+            sa.sageattn_qk_int8_pv_fp8_cuda(*big, is_causal=(it % 2 == 0))
+        elif it % 3 == 1:
+            torch.mm(big[0].view(-1, 128)[:8192].float(), big[1].view(-1, 128)[:8192].float().t())
+        o, l = fn(q, k, v, is_causal=causal, return_lse=True)
+        eo, el = torch.equal(o, o0), torch.equal(l, l0)
+        if not (eo and el):
+            nd += 1
+            if first is None:
+                d = (o.float() - o0.float()).abs(); bad = (d > 0).nonzero()
+                dl = (l - l0).abs(); badl = (dl > 0).nonzero()
+                first = (it, "o", d.max().item(), bad.shape[0], bad[:2].tolist(), sorted(set(bad[:, 2].tolist()))[:6],
+                         "lse", dl.max().item(), badl.shape[0], badl[:2].tolist())
+    print((B, H, N, D, causal, pv), "nondeterministic", nd, "/", runs, first, flush=True)
