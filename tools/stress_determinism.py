@@ -12,6 +12,7 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 if len(sys.argv) > 2:  # "nofuse": Q quantizer as a separate kernel
     sa.core.FUSE_Q_QUANT = sys.argv[2] != "nofuse"
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+gran = sys.argv[4] if len(sys.argv) > 4 else "per_thread"
 torch.manual_seed(23)
 big = [torch.randn(4, 32, 8192, 128, dtype=torch.float16, device="cuda") for _ in range(3)]
 cfgs = [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8"),
@@ -19,14 +20,14 @@ cfgs = [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32,
 for (B, H, N, D, causal, pv) in (cfgs if only is None else cfgs[only:only + 1]):
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
     fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
-    o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
+    o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True, qk_quant_gran=gran)
     nd, first = 0, None
     for it in range(runs):
         if it % 3 == 0:
             sa.sageattn_qk_int8_pv_fp8_cuda(*big, is_causal=(it % 2 == 0))
         elif it % 3 == 1:
             torch.mm(big[0].view(-1, 128)[:8192].float(), big[1].view(-1, 128)[:8192].float().t())
-        o, l = fn(q, k, v, is_causal=causal, return_lse=True)
+        o, l = fn(q, k, v, is_causal=causal, return_lse=True, qk_quant_gran=gran)
         eo, el = torch.equal(o, o0), torch.equal(l, l0)
         if not (eo and el):
             nd += 1
