@@ -337,6 +337,27 @@ def test_sageattn_dispatch_rule(sa, monkeypatch):
         sa.sageattn(q, k, v)
 
 
+@pytest.mark.parametrize("cfg", [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8")])
+def test_determinism_under_perturbed_timing(sa, cfg):
+    """As test_run_to_run_determinism, for the three-waves-per-SIMD instantiations, with a DIFFERENT heavy kernel
+    between the checked launches (clock, cache and co-residency state change from launch to launch): steady-state
+    repetition alone did not expose the register-reuse and fused-prologue problems found in round 1
+    (tools/stress_determinism.py is the long form)."""
+    B, H, N, D, causal, pv = cfg
+    torch.manual_seed(31)
+    big = [torch.randn(4, 32, 4096, 128, dtype=torch.float16, device="cuda") for _ in range(3)]
+    q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
+    for it in range(150):
+        if it % 3 == 0:
+            sa.sageattn_qk_int8_pv_fp8_cuda(*big, is_causal=(it % 2 == 0))
+        elif it % 3 == 1:
+            torch.mm(big[0].view(-1, 128)[:4096].float(), big[1].view(-1, 128)[:4096].float().t())
+        o, l = fn(q, k, v, is_causal=causal, return_lse=True)
+        assert torch.equal(o, o0) and torch.equal(l, l0), f"launch {it} differs"
+
+
 def test_full_size_c4_fp8_causal_properties(sa):
     """BASELINE configs[3] = (4,32,16384,128), INT8 QK^T + FP8 PV, causal, at full size, through properties that do
     not need an O(N^2) reference for the whole tensor: (1) V = 1 => O = 1; (2) causality: with K smoothing off, the
