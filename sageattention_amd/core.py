@@ -84,12 +84,12 @@ _GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_warp": L.GRAN_PER_WARP, "per_t
 
 # Fold the Q quantizer into the attention kernel (sage_attn_fusedq_*): same bits, one launch and one pass over Q less.
 # Measured in-process (tools/ab_e2e.py): +2..4 % end to end at (4,32,2048,64), neutral at (4,32,8192,128) where the
-# per-workgroup prologue latency (one workgroup per CU) costs what the saved launch gains.
-# OPT-IN (SAGEATTN_FUSE_Q=1 or core.FUSE_Q_QUANT = True): under perturbed timing (a different heavy kernel between
-# launches, tools/stress_determinism.py) the fused prologue gave a wrong 32-row wave about once in 300 launches at
-# head_dim 64 / causal, while the stand-alone quantizer + kernel path gave 0 in 1500 and the kernel alone 0 in 3000.
-# The cause is not yet found (the always-exact form of the prologue does not show it), so the default is the clean path.
-FUSE_Q_QUANT = os.environ.get("SAGEATTN_FUSE_Q", "0") == "1"
+# per-workgroup prologue latency (one workgroup per CU) costs what the saved launch gains -- hence FUSE_Q_MAX_SEQ.
+# Default ON since round 2: the rare wrong 32-row wave seen under perturbed timing in round 1 was an LDS race in the
+# attention kernel's prologue (K buffer 0 re-filled before every wave had read it), fixed by one barrier; the fused
+# prologue only widened the window.  Evidence: profiles/r02_race_evidence.md.  SAGEATTN_FUSE_Q=0 selects the
+# stand-alone Q quantizer + kernel path (bit-identical results).
+FUSE_Q_QUANT = os.environ.get("SAGEATTN_FUSE_Q", "1") == "1"
 FUSE_Q_MAX_SEQ = 4096
 
 

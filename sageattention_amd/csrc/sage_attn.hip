@@ -322,13 +322,19 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // the pin, so that one keeps it).
   constexpr bool BIAS_RESIDENT = !HAS_MASK && (D == 128 || (!PV_FP8 && !CAUSAL));
   if constexpr (BIAS_RESIDENT) asm volatile("" : "+v"(bias));
-  // First k-step of an S^T chain: acc = bias + K.Q^T.  The C operand must NOT be a temporary that dies when the MFMA
-  // issues: hipcc then reuses those registers for VALU results after the 7 wait states its hazard table assumes for an
-  // 8-pass MFMA, and on MI355X with three waves per SIMD queueing on the matrix pipe that was measured to corrupt C
-  // (nondeterministic rows at head_dim 64 causal, 81 of 100 runs).  So C is either the resident bias tuple, which
-  // nothing ever writes, or the MFMA's own destination registers initialised in place (C = D).
+  // First k-step of an S^T chain: acc = bias + K.Q^T.  C is either the resident bias tuple or the MFMA's own destination
+  // registers initialised in place (C = D), so the chain never needs a second 16-register tuple.
+  // History: round 1 blamed nondeterministic rows at head_dim 64 / causal on hipcc re-using a temporary C tuple too early
+  // and introduced this form as the fix.  That diagnosis was wrong: the cause was the missing barrier between the
+  // prologue S(0) and the first K(2) copy (below; profiles/r02_race_evidence.md).  With the barrier in place the old
+  // form (-DSAGE_EXP_CTEMP) is bit-stable too (0 of 100 + 0 of 1000 stressed launches); this form stays because it is
+  // what every test and profile of the kernel ran on.
   auto mfma_s_first = [&](const v4i a, const v4i b) __attribute__((always_inline)) -> v16i {
+#ifdef SAGE_EXP_CTEMP
+    if constexpr (true) {  // probe: the round-1 form (C = a re-materialised temporary) that was blamed for the corruption
+#else
     if constexpr (BIAS_RESIDENT) {
+#endif
       return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, bias, 0, 0, 0);
     } else {
       v16i acc = bias;
@@ -635,7 +641,20 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   } else {
   v16i s_cur[2], s_nxt[2];
   float sc0, sc1, mx_cur;
+#ifdef SAGE_EXP_DELAY_WAVE
+  // mechanism probe (tools/race_probe.sh): hold one wave back for a few microseconds between the prologue barrier and
+  // its K(0) fragment reads, i.e. force the interleaving that the missing barrier below allowed
+  if (wave == 1) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+#endif
   qk(0, s_cur);
+  // Every wave reads ALL 64 rows of K buffer 0 for S(0) above, and iteration 0 below re-fills that buffer with K(2)
+  // (each wave DMA-writes its own 1 KiB slice).  Later iterations are ordered by the barrier that closes the previous
+  // one; this first re-fill needs its own: without it a wave that is held back between the prologue barrier and its
+  // K(0) fragment reads (three waves per SIMD: the youngest wave can starve for longer than an L2 round trip) computes
+  // S(0) from a mix of K(0) and K(2) rows -- one wrong 32-row wave, the same wrong value every time.
+#ifndef SAGE_EXP_NO_PROLOGUE_BARRIER
+  __syncthreads();
+#endif
   tile_scales(0, sc0, sc1);
   mask_limit(0, s_cur);
   mx_cur = row_max(s_cur, sc0, sc1);

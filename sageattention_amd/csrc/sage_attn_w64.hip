@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void attn_i8_w64_kernel(const AttnParams p)
   float sc_cur[QT][2], sc_nxt[QT][2], mx_cur[QT];
   qk(0, s_cur);
   drain_s(s_cur);
+  __syncthreads();  // all waves are done reading K buffer 0 before iteration 0 re-fills it with K(2) (see sage_attn.hip)
   scales_from(load_kscales(0), sc_cur);
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {

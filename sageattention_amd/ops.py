@@ -28,13 +28,15 @@ def _entry(pv: str):
 @torch.library.custom_op("sageattention_amd::attn", mutates_args=())
 def attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str, is_causal: bool, sm_scale: float,
          pv: str, qk_quant_gran: str) -> torch.Tensor:
+    # contiguous result whatever the inputs' strides / head-dim padding: the fake implementation below must describe
+    # exactly the layout the real op returns, or Inductor indexes the output with the wrong strides
     return _entry(pv)(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
-                      qk_quant_gran=qk_quant_gran)
+                      qk_quant_gran=qk_quant_gran).contiguous()
 
 
 @attn.register_fake
 def _(q, k, v, tensor_layout, is_causal, sm_scale, pv, qk_quant_gran):
-    return torch.empty_like(q)
+    return q.new_empty(q.shape)
 
 
 @torch.library.custom_op("sageattention_amd::attn_lse", mutates_args=())
@@ -42,7 +44,7 @@ def attn_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
              pv: str, qk_quant_gran: str) -> Tuple[torch.Tensor, torch.Tensor]:
     o, lse = _entry(pv)(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
                         qk_quant_gran=qk_quant_gran, return_lse=True)
-    return o, lse
+    return o.contiguous(), lse
 
 
 @attn_lse.register_fake
@@ -51,7 +53,7 @@ def _(q, k, v, tensor_layout, is_causal, sm_scale, pv, qk_quant_gran):
         B, H, M = q.shape[0], q.shape[1], q.shape[2]
     else:
         B, M, H = q.shape[0], q.shape[1], q.shape[2]
-    return torch.empty_like(q), q.new_empty((B, H, M), dtype=torch.float32)
+    return q.new_empty(q.shape), q.new_empty((B, H, M), dtype=torch.float32)
 
 
 def sageattn_compilable(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND",

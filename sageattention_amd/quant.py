@@ -20,15 +20,13 @@ def _km3(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torch.Tenso
 
 
 def _quant(x, tensor_layout, gran, is_key, blk, warp, mult, rounding, mean=None, dot_vec=None, dot_group=1,
-           dense_heads=False):
+           dense_heads=False, out=None, scale=None):
     """dense_heads: for an NHD input, give the int8 result head-major storage ([B,H,N,D] contiguous, returned as its
     [B,N,H,D] view): it is an internal operand of the attention kernel, which then streams K/Q rows of one head from
-    consecutive lines instead of one line per H*D bytes (the C ABI takes strides per tensor)."""
+    consecutive lines instead of one line per H*D bytes (the C ABI takes strides per tensor).
+    out / scale: caller-allocated results (the reference's pybind convention, quant.py:73-90; the ring quantizes
+    straight into its send buffer)."""
     B, H, N, D = L.dims(x, tensor_layout)
-    if dense_heads and tensor_layout == "NHD":
-        out = torch.empty((B, H, N, D), dtype=torch.int8, device=x.device).transpose(1, 2)
-    else:
-        out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
     nblk = (N + blk - 1) // blk
     if gran == L.GRAN_PER_BLOCK:
         G = nblk
@@ -36,7 +34,17 @@ def _quant(x, tensor_layout, gran, is_key, blk, warp, mult, rounding, mean=None,
         G = nblk * (blk // warp)
     else:
         G = nblk * (blk // warp) * (4 if is_key else 8)
-    scale = torch.empty((B, H, G), dtype=torch.float32, device=x.device)
+    if out is None:
+        if dense_heads and tensor_layout == "NHD":
+            out = torch.empty((B, H, N, D), dtype=torch.int8, device=x.device).transpose(1, 2)
+        else:
+            out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    elif out.dtype != torch.int8 or out.shape != x.shape or out.device != x.device or out.stride(-1) != 1:
+        raise ValueError("out must be an int8 tensor of the input's shape on its device with a contiguous last dim")
+    if scale is None:
+        scale = torch.empty((B, H, G), dtype=torch.float32, device=x.device)
+    elif scale.dtype != torch.float32 or scale.numel() != B * H * G or not scale.is_contiguous():
+        raise ValueError(f"scale must be a contiguous float32 tensor with {B * H * G} elements")
     dot = torch.empty((B, H, N), dtype=torch.float32, device=x.device) if dot_vec is not None else None
     xd, od = L.desc(x, tensor_layout), L.desc(out, tensor_layout)
     st = L.lib().sage_quant_qk_int8(xd, L.dtype_code(x.dtype), B, H, N, D, L.ptr(mean), od, scale.data_ptr(),

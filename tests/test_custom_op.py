@@ -81,3 +81,37 @@ def test_operator_captures_into_a_hip_graph(pv):
         torch.cuda.synchronize()
         o_e, l_e = fn(q, k, v, is_causal=True, return_lse=True)
         assert torch.equal(o_g, o_e) and torch.equal(l_g, l_e)
+
+
+def test_fake_output_is_contiguous_for_strided_inputs():
+    """The real op returns a freshly allocated contiguous tensor (also when the head dim was padded or q is a strided
+    view); the fake must describe that layout, not q's."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        q = torch.empty((2, 100, 8, 96), dtype=torch.float16, device="cuda").transpose(1, 2)  # HND view of NHD memory
+        o = ops.sageattn_compilable(q, q, q, pv="fp16")
+        assert o.shape == q.shape and o.is_contiguous()
+
+
+@pytest.mark.gpu
+def test_compiles_at_padded_head_dim_and_strided_q():
+    """head_dim 96 (padded to 128 inside, output sliced back) and a transposed q: real and fake layouts agree, so the
+    compiled graph (inductor included) indexes the result correctly."""
+    import sageattention_amd as sa
+    torch.manual_seed(0)
+    q = torch.randn(1, 200, 4, 96, dtype=torch.float16, device="cuda").transpose(1, 2)
+    k = torch.randn(1, 4, 260, 96, dtype=torch.float16, device="cuda")
+    v = torch.randn(1, 4, 260, 96, dtype=torch.float16, device="cuda")
+
+    def block(q, k, v):
+        return ops.sageattn_compilable(q, k, v, pv="fp16") * 2.0
+
+    want = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v) * 2.0
+    for backend in ("aot_eager", "inductor"):
+        try:
+            got = torch.compile(block, backend=backend, fullgraph=True)(q, k, v)
+        except torch._dynamo.exc.BackendCompilerFailed:
+            if backend == "inductor":   # no usable code generator for the surrounding pointwise op on this box
+                continue
+            raise
+        assert got.shape == want.shape and torch.equal(got, want), backend

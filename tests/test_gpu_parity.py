@@ -258,8 +258,8 @@ def test_full_size_properties(sa):
 
 @pytest.mark.parametrize("cfg", [
     # (B, H, N, D, causal, pv, w64)
-    (4, 32, 2048, 64, True, "fp16", False),   # three waves per SIMD, bias tuple not resident: the configuration that
-    (4, 32, 2048, 64, True, "fp8", False),    # once corrupted the C operand of the first S MFMA (see sage_attn.hip)
+    (4, 32, 2048, 64, True, "fp16", False),   # three waves per SIMD: the configuration in which the round-1 prologue
+    (4, 32, 2048, 64, True, "fp8", False),    # race (K buffer 0 re-filled too early, see sage_attn.hip) showed
     (4, 32, 2048, 64, False, "fp8", False),
     (2, 16, 4096, 128, True, "fp16", False),
     (2, 16, 4096, 128, True, "fp8", False),
@@ -267,8 +267,7 @@ def test_full_size_properties(sa):
 ])
 def test_run_to_run_determinism(sa, cfg):
     """The operator is a pure function of its inputs: 40 launches on the same tensors, with the whole chip busy (so that
-    waves queue on the matrix pipe), must give bit-identical outputs and LSE.  Guards the register-reuse hazard class:
-    an MFMA source operand that the compiler may overwrite while the instruction is still in flight."""
+    waves queue on the matrix pipe), must give bit-identical outputs and LSE."""
     from sageattention_amd import _lib as L
     B, H, N, D, causal, pv, w64 = cfg
     torch.manual_seed(23)
@@ -337,25 +336,33 @@ def test_sageattn_dispatch_rule(sa, monkeypatch):
         sa.sageattn(q, k, v)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("cfg", [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8")])
-def test_determinism_under_perturbed_timing(sa, cfg):
+def test_determinism_under_perturbed_timing(sa, cfg, fused):
     """As test_run_to_run_determinism, for the three-waves-per-SIMD instantiations, with a DIFFERENT heavy kernel
-    between the checked launches (clock, cache and co-residency state change from launch to launch): steady-state
-    repetition alone did not expose the register-reuse and fused-prologue problems found in round 1
-    (tools/stress_determinism.py is the long form)."""
+    between the checked launches (clock, cache and co-residency state change from launch to launch), through the
+    fused-Q entry points (the default) and through quantizer + kernel.  This is the regime in which the round-1
+    kernel returned a wrong 32-row wave about once in 150-300 launches: K buffer 0 was re-filled with K(2) before
+    every wave had read K(0) (sage_attn.hip, barrier after the prologue S(0); profiles/r02_race_evidence.md;
+    tools/stress_determinism.py is the long form: 0 in 3000 after the fix, 8 in 1200 without it)."""
     B, H, N, D, causal, pv = cfg
     torch.manual_seed(31)
     big = [torch.randn(4, 32, 4096, 128, dtype=torch.float16, device="cuda") for _ in range(3)]
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
     fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
-    o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
-    for it in range(150):
-        if it % 3 == 0:
-            sa.sageattn_qk_int8_pv_fp8_cuda(*big, is_causal=(it % 2 == 0))
-        elif it % 3 == 1:
-            torch.mm(big[0].view(-1, 128)[:4096].float(), big[1].view(-1, 128)[:4096].float().t())
-        o, l = fn(q, k, v, is_causal=causal, return_lse=True)
-        assert torch.equal(o, o0) and torch.equal(l, l0), f"launch {it} differs"
+    keep = sa.core.FUSE_Q_QUANT
+    try:
+        sa.core.FUSE_Q_QUANT = fused
+        o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
+        for it in range(150):
+            if it % 3 == 0:
+                sa.sageattn_qk_int8_pv_fp8_cuda(*big, is_causal=(it % 2 == 0))
+            elif it % 3 == 1:
+                torch.mm(big[0].view(-1, 128)[:4096].float(), big[1].view(-1, 128)[:4096].float().t())
+            o, l = fn(q, k, v, is_causal=causal, return_lse=True)
+            assert torch.equal(o, o0) and torch.equal(l, l0), f"launch {it} differs"
+    finally:
+        sa.core.FUSE_Q_QUANT = keep
 
 
 def test_full_size_c4_fp8_causal_properties(sa):
@@ -601,7 +608,7 @@ def test_fused_q_quantizer_is_bit_identical(sa, golden, gran, pv):
     assert m["M"] <= core.FUSE_Q_MAX_SEQ
     keep = core.FUSE_Q_QUANT
     try:
-        core.FUSE_Q_QUANT = True    # opt-in path (core.py)
+        core.FUSE_Q_QUANT = True    # the default path (core.py)
         o1, l1 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
         core.FUSE_Q_QUANT = False
         o0, l0 = fn(g.q.cuda(), g.k.cuda(), g.v.cuda(), **kw)
@@ -654,3 +661,44 @@ def test_randomized_sweep_vs_oracle(sa):
                ("fp8", torch.bfloat16): 0.07}[(pv, dt)]
         assert (o.cpu().float() - oo.float()).abs().max() < tol, cfg
         assert (lse.cpu() - ol).abs().max() < 3e-3, cfg
+
+
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_sub_mean_bit_exact_vs_oracle(sa, layout, dt):
+    """``sub_mean`` (reference quant.py:183-223, fused.cu:200-260) against ``oracle.sub_mean``: the mean within one ulp
+    of the storage dtype (summation order differs from torch's), the smoothed tensor BIT-exact given that mean
+    (subtraction in the input dtype, bf16 results converted to fp16).  CUDA-only in the reference: parity unpinned."""
+    from oracle import sage_oracle as O
+    torch.manual_seed(11)
+    B, H, N, D = 2, 3, 333, 128
+    shape = (B, H, N, D) if layout == "HND" else (B, N, H, D)
+    v = (torch.randn(shape) * 2 + torch.randn(1, 1, 1, D) * 3).to(dt)
+    vs, vm = sa.quant.sub_mean(v.cuda(), layout)
+    assert vs.dtype == torch.float16 and vs.shape == v.shape and vm.shape == (B, H, D) and vm.dtype == dt
+    _, vm_ref = O.sub_mean(v, layout)
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    assert ((vm.cpu().float() - vm_ref.float()).abs() <= ulp * vm_ref.float().abs().clamp(min=2.0 ** -14)).all()
+    vs_ref, _ = O.sub_mean(v, layout, vm=vm.cpu())
+    assert torch.equal(vs.cpu(), vs_ref)
+
+
+@pytest.mark.parametrize("gran", ["per_thread", "per_warp"])
+def test_c3_headline_config_vs_oracle(sa, gran):
+    """BASELINE configs[2] = (4,32,8192,128), INT8 QK^T + FP16 PV -- the shape bench.py times, through the 8-wave
+    instantiation it times -- with a random V at full size against the oracle on two whole heads (first head of the
+    first batch, last head of the last): |do| <= 2e-3 (fp16 output, fp32 accumulation on both sides; the tile order
+    and the lazy rescale differ), LSE <= 2e-3.  Non-causal and causal."""
+    from oracle import sage_oracle as O
+    torch.manual_seed(5)
+    B, H, N, D = 4, 32, 8192, 128
+    q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") + torch.randn(1, H, 1, D, dtype=torch.float16, device="cuda")
+    v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    for causal in (False, True):
+        o, lse = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=causal, qk_quant_gran=gran, return_lse=True)
+        for sl in ((slice(0, 1), slice(0, 1)), (slice(3, 4), slice(31, 32))):
+            oo, ol = O.sageattn_oracle(q[sl].cpu(), k[sl].cpu(), v[sl].cpu(), qk_quant_gran=gran, is_causal=causal,
+                                       return_lse=True)
+            assert (o[sl].cpu().float() - oo.float()).abs().max() < 2e-3
+            assert (lse[sl].cpu() - ol).abs().max() < 2e-3
