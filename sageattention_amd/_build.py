@@ -13,8 +13,10 @@ ARCH = "gfx950"
 # (source, extra flags).  The quantizers need exact IEEE semantics (bit-exact vs the oracle).
 SOURCES = [
     ("sage_quant.hip", ["-ffp-contract=off"]),
-    ("sage_attn.hip", ["-fno-slp-vectorize"]),  # packed f32 VALU is slower beside MFMAs
-    ("sage_attn_w64.hip", ["-fno-slp-vectorize"]),
+    # packed f32 VALU is slower beside MFMAs; contraction off: the fused Q-quantizer prologue must round exactly like
+    # K1 (sage_quant.hip) -- the tile loop spells its fmas out (__builtin_fmaf), so it is unaffected
+    ("sage_attn.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
+    ("sage_attn_w64.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
 ]
@@ -66,8 +68,8 @@ def build_variant(out: str, extra_flags, verbose: bool = False) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "sage_common.h"), os.path.join(CSRC, "sage_attn_common.h"),
-            os.path.join(HERE, "..", "include", "sageattn_hip.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "sageattn_hip.h"))
     objs = []
     procs = []
     for src, extra in SOURCES:

@@ -18,6 +18,7 @@
 // Roofline: MFMA (4*M*N*D flop per (b,h); half int8 at 2x the fp16 rate), VALU/exp2 co-limited.
 // Algorithmic HBM bytes per (b,h): M*D (Q) + N*D (K) + 2*N*D (V fp16) + 2*M*D (O) + scales.
 #include "sage_attn_common.h"
+#include "sage_attn_ablate.h"
 
 namespace sage {
 
@@ -25,9 +26,6 @@ namespace sage {
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
 template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8, bool HAS_MASK>
-#ifndef SAGE_MINWAVES
-#define SAGE_MINWAVES 2
-#endif
 __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(const AttnParams p) {
   static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
   static_assert(!HAS_MASK || (!CAUSAL && !PV_FP8 && !V_BF16), "attn_mask: non-causal fp16-PV operator, fp16 V");
@@ -66,9 +64,17 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     const int q_lo = p.cu_q[b], k_lo = p.cu_k[b];
     M_ = p.cu_q[b + 1] - q_lo;
     N_ = p.cu_k[b + 1] - k_lo;
-    if (qb * QB >= M_ || N_ <= 0) return;
+    if (qb * QB >= M_) return;
     q_boff = (int64_t)q_lo * p.qsn; o_boff = (int64_t)q_lo * p.osn;
     k_boff = (int64_t)k_lo * p.ksn; v_boff = (int64_t)k_lo * p.vsn;
+    if (N_ <= 0) {  // a sequence with queries but no keys: the reference stores zeros (acc = 0, l_i = 1;
+                    // attn_qk_int8_block_varlen.py:109-121), it does not leave the rows unwritten
+      const int rows = min(QB, M_ - qb * QB);
+      uint16_t* ob = p.o + o_boff + h * p.osh + (int64_t)(qb * QB) * p.osn;
+      for (int i = threadIdx.x; i < rows * (D / 4); i += T)
+        *reinterpret_cast<uint2*>(ob + (int64_t)(i / (D / 4)) * p.osn + (i % (D / 4)) * 4) = make_uint2(0u, 0u);
+      return;
+    }
   }
 
   const int tid = threadIdx.x;
@@ -236,9 +242,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   }
   // K(j) -> K buffer `buf`
   auto dma_k = [&](int j, const int buf) __attribute__((always_inline)) {
-#ifdef SAGE_ABL_SAMETILE
-    j = 0;  // timing-only ablation: every copy re-reads tile 0 (vector-L1 hits): what the L2 latency of the copies costs
-#endif
+    if constexpr (abl::kSameTile) j = 0;
 #pragma unroll
     for (int i = 0; i < KC; ++i)
       if (KC * T == 64 * KCH || wave * 64 + i * T < 64 * KCH)
@@ -246,9 +250,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   };
   // V(j) -> V buffer `buf` (DMA), or -> registers (bf16 path; written to LDS by store_v)
   auto load_v = [&](int j, const int buf) __attribute__((always_inline)) {
-#ifdef SAGE_ABL_SAMETILE
-    j = 0;
-#endif
+    if constexpr (abl::kSameTile) j = 0;
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
       if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
@@ -330,11 +332,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // form (-DSAGE_EXP_CTEMP) is bit-stable too (0 of 100 + 0 of 1000 stressed launches); this form stays because it is
   // what every test and profile of the kernel ran on.
   auto mfma_s_first = [&](const v4i a, const v4i b) __attribute__((always_inline)) -> v16i {
-#ifdef SAGE_EXP_CTEMP
-    if constexpr (true) {  // probe: the round-1 form (C = a re-materialised temporary) that was blamed for the corruption
-#else
-    if constexpr (BIAS_RESIDENT) {
-#endif
+    if constexpr (BIAS_RESIDENT || abl::kCTemp) {
       return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, bias, 0, 0, 0);
     } else {
       v16i acc = bias;
@@ -349,12 +347,12 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-#ifdef SAGE_ABL_NOQK
-        s[mt] = bias; s[mt][0] += kbuf + ks;
-#else
-        const v4i a = *reinterpret_cast<const v4i*>(k_lds + kbuf * KBYTES + mt * 32 * D + k_rd[ks]);
-        s[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s[mt], 0, 0, 0);
-#endif
+        if constexpr (abl::kNoQK) {
+          s[mt] = bias; s[mt][0] += kbuf + ks;
+        } else {
+          const v4i a = *reinterpret_cast<const v4i*>(k_lds + kbuf * KBYTES + mt * 32 * D + k_rd[ks]);
+          s[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s[mt], 0, 0, 0);
+        }
       }
   };
   // dequantisation scales of tile j: …sm80.cu:131, 4 per 64 keys, index (c%8)/2 = 2*hh + ((reg&3)>>1)
@@ -521,11 +519,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       if (MASKED && fmask) {
         pv = __builtin_amdgcn_exp2f(__int_as_float(s[mt][e]) - m_run + kPOff);  // registers hold fp32 logits
       } else {
-#ifdef SAGE_ABL_NOEXP
         pv = __builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0);
-#else
-        pv = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(s[mt][e]), g1 ? sc1 : sc0, g1 ? c1 : c0));
-#endif
+        if constexpr (!abl::kNoExp) pv = __builtin_amdgcn_exp2f(pv);
       }
       return pv;
     };
@@ -554,11 +549,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
             v8h a;
             a.s0123 = __builtin_bit_cast(v4h, lo);
             a.s4567 = __builtin_bit_cast(v4h, hi);
-#ifdef SAGE_ABL_NOPV
-            asm volatile("" ::"v"(a), "v"(pf));
-#else
-            acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, acc_o[dt], 0, 0, 0);
-#endif
+            if constexpr (abl::kNoPV) asm volatile("" ::"v"(a), "v"(pf));
+            else acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, acc_o[dt], 0, 0, 0);
           }
         }
     } else {
@@ -599,16 +591,11 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   int n_plain = wave_tiles;
   if (N_ & 63) n_plain = min(n_plain, N_ >> 6);
   if constexpr (CAUSAL) n_plain = min(n_plain, max(0, (q0 + 1) >> 6));  // tile j needs no mask iff 64*j+63 <= q0
-#ifdef SAGE_ABL_ALLGENERIC
-  const int n_fast = 0;  // cross-check build: every tile through the generic body (results must not change by one bit)
-#else
-  const int n_fast = (CAN_MASK && p.mask) ? 0 : max(0, min(n_plain - 1, wave_tiles - 1));  // attn_mask: all tiles generic
-#endif
+  const int n_fast = (abl::kAllGeneric || (CAN_MASK && p.mask)) ? 0 : max(0, min(n_plain - 1, wave_tiles - 1));  // attn_mask: all tiles generic
 
-#ifdef SAGE_EXP_PRIO
-  // experiment: static priority for the second-dispatched half of the workgroup (MI355X guide, two waves per SIMD item 4)
-  if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(SAGE_EXP_PRIO);
-#endif
+  if constexpr (abl::kPrio >= 0) {  // static priority for the second-dispatched half of the workgroup: measured 0 %
+    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(abl::kPrio >= 0 ? abl::kPrio : 0);
+  }
   dma_k(0, 0);
   load_v(0, 0);
   store_v(0);
@@ -641,20 +628,16 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   } else {
   v16i s_cur[2], s_nxt[2];
   float sc0, sc1, mx_cur;
-#ifdef SAGE_EXP_DELAY_WAVE
-  // mechanism probe (tools/race_probe.sh): hold one wave back for a few microseconds between the prologue barrier and
-  // its K(0) fragment reads, i.e. force the interleaving that the missing barrier below allowed
-  if (wave == 1) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
-#endif
+  if constexpr (abl::kDelayWave) {  // mechanism probe: force the interleaving that the missing barrier below allowed
+    if (wave == 1) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+  }
   qk(0, s_cur);
   // Every wave reads ALL 64 rows of K buffer 0 for S(0) above, and iteration 0 below re-fills that buffer with K(2)
   // (each wave DMA-writes its own 1 KiB slice).  Later iterations are ordered by the barrier that closes the previous
   // one; this first re-fill needs its own: without it a wave that is held back between the prologue barrier and its
   // K(0) fragment reads (three waves per SIMD: the youngest wave can starve for longer than an L2 round trip) computes
   // S(0) from a mix of K(0) and K(2) rows -- one wrong 32-row wave, the same wrong value every time.
-#ifndef SAGE_EXP_NO_PROLOGUE_BARRIER
-  __syncthreads();
-#endif
+  if constexpr (!abl::kNoPrologueBarrier) __syncthreads();
   tile_scales(0, sc0, sc1);
   mask_limit(0, s_cur);
   mx_cur = row_max(s_cur, sc0, sc1);
@@ -665,21 +648,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
                        float& b1) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;  // j & 1, static so every LDS offset is an immediate
     maybe_rescale(mx_cur);
-#ifndef SAGE_ABL_NOSTAGE
-    if (j + 2 < ntiles) dma_k(j + 2, PAR);
-    load_v(j + 1, PAR ^ 1);
-#endif
+    if constexpr (!abl::kNoStage) {
+      if (j + 2 < ntiles) dma_k(j + 2, PAR);
+      load_v(j + 1, PAR ^ 1);
+    }
     // scales of tile j+1 were fetched during the previous iteration; fetch those of tile j+2 now (a scalar load
     // issued right in front of its use would expose the scalar-cache latency behind the workgroup barrier)
     scales_from(kk_nxt, b0, b1);
     kk_nxt = load_kscales(min(j + 2, ntiles - 1));
-#ifdef SAGE_SCHED_COMPILER
-    constexpr int HAND_PLACED = 0;
-#elif defined(SAGE_SCHED_COMPILER_FP8)
-    constexpr int HAND_PLACED = PV_FP8 ? 0 : 1;
-#else
-    constexpr int HAND_PLACED = PV_FP8 ? 2 : 1;
-#endif
+    constexpr int HAND_PLACED = PV_FP8 ? abl::kHandPlacedF8 : abl::kHandPlacedF16;
     if constexpr (HAND_PLACED == 0) {
       qk(PAR ^ 1, sb);
       softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
@@ -775,15 +752,11 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       const char* const vb = v_lds + PAR * VBYTES;
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
-#ifdef SAGE_ABL_NOLDSK
-        return qf[i % KS];  // timing-only ablation: no K fragment reads
-#endif
-        return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
+        if constexpr (abl::kNoLdsK) return qf[i % KS];
+        else return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
       };
       auto v_frag = [&](const int q, const int dt) __attribute__((always_inline)) -> v8h {
-#ifdef SAGE_ABL_NOLDSV
-        return __builtin_bit_cast(v8h, qf[(q + dt) % KS]);  // timing-only ablation: no V fragment reads
-#endif
+        if constexpr (abl::kNoLdsV) return __builtin_bit_cast(v8h, qf[(q + dt) % KS]);
         const char* base = vb + 16 * q * (2 * D) + v_rd[dt];
         const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
         const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
@@ -872,13 +845,11 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
       mx_cur = swap_max(mx);
     }
-#ifndef SAGE_ABL_NOSTAGE
-    store_v(PAR ^ 1);
-    dma_wait_all();
-#endif
-#ifndef SAGE_ABL_NOBAR
-    __syncthreads();
-#endif
+    if constexpr (!abl::kNoStage) {
+      store_v(PAR ^ 1);
+      dma_wait_all();
+    }
+    if constexpr (!abl::kNoBar) __syncthreads();
   };
   float nsc0 = 0.f, nsc1 = 0.f;
   int j = 0;
@@ -886,11 +857,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
     fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
-#ifndef SAGE_NO_ODD_FAST
   // an odd fast tile left (j is even here): one more fast iteration instead of a generic one (+11 % at C2, where the
   // generic body otherwise takes 2 of 32 tiles).  Not for the register-staged bf16 V variants: the third copy of the
   // fast body pushes them into scratch.
-  if constexpr (!V_BF16) {
+  if constexpr (!V_BF16 && !abl::kNoOddFast) {
     if (j < n_fast) {
       fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
       s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
@@ -898,7 +868,6 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       ++j;
     }
   }
-#endif
   for (; j < wave_tiles; ++j) {
     maybe_rescale(mx_cur);
     if (j + 2 < ntiles) dma_k(j + 2, j & 1);
@@ -968,6 +937,13 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   }
 }
 
+// dynamic LDS above the 48 KiB default needs the function attribute; its status is part of the launch status
+static bool allow_lds(const void* kern, size_t bytes) {
+  launch_begin();
+  return bytes <= 48 * 1024 ||
+         hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 template <int D, int NWAVES, bool PV_FP8>
 static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf16, hipStream_t st) {
   if constexpr (!PV_FP8) {
@@ -976,11 +952,11 @@ static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf
       const dim3 grid_m(p.nqb * p.Hq * p.B), block_m(NWAVES * 64);
       if (kthread) {
         auto kern = attn_i8_kernel<D, NWAVES, false, true, false, false, true>;
-        if (smem_m > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
+        if (!allow_lds((const void*)kern, smem_m)) return SAGE_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);
       } else {
         auto kern = attn_i8_kernel<D, NWAVES, false, false, false, false, true>;
-        if (smem_m > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m);
+        if (!allow_lds((const void*)kern, smem_m)) return SAGE_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);
       }
       return launch_status();
@@ -991,7 +967,7 @@ static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf
 #define SAGE_LAUNCH(C, K, V)                                                                                       \
   do {                                                                                                             \
     auto kern = attn_i8_kernel<D, NWAVES, C, K, V, PV_FP8, false>;                                                      \
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    if (!allow_lds((const void*)kern, smem)) return SAGE_ERR_LAUNCH;                                                   \
     hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                            \
   } while (0)
 #define SAGE_BY_V(C, K)                                                                                            \

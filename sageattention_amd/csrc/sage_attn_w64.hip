@@ -567,7 +567,8 @@ int launch_attn_w64(const AttnParams& p_in, int D, bool causal, bool kthread, bo
 #define SAGE_W64(C, K)                                                                                              \
   do {                                                                                                              \
     auto kern = attn_i8_w64_kernel<128, C, K>;                                                                      \
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
+    launch_begin();                                                                                              \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SAGE_ERR_LAUNCH; \
     hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                             \
   } while (0)
   if (causal) { if (kthread) SAGE_W64(true, true); else SAGE_W64(true, false); }

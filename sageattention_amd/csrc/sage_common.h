@@ -55,6 +55,9 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
   }
 }
 
+// hipGetLastError() is sticky per host thread: every entry point clears it before its first launch (launch_begin), so
+// that launch_status() reports THIS call's launches and not a stale error of an earlier, unrelated runtime call.
+__host__ inline void launch_begin() { (void)hipGetLastError(); }
 __host__ inline int launch_status() {
   return hipGetLastError() == hipSuccess ? SAGE_OK : SAGE_ERR_LAUNCH;
 }

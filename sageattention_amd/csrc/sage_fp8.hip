@@ -140,6 +140,7 @@ extern "C" int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, i
   float* part = (float*)workspace;
   float* coef = part + (size_t)B * H * S * 3 * D;
   hipStream_t st = (hipStream_t)stream;
+  launch_begin();
   const uint16_t* vp = (const uint16_t*)v->data;
   const dim3 g1(S, H, B), g2((N + 63) / 64, H, B);
 #define L1(DD, BF) hipLaunchKernelGGL((v_stats_partial_kernel<DD, BF>), g1, dim3(256), 0, st, vp, v->stride_b, v->stride_h, v->stride_n, N, part, S)

@@ -105,6 +105,7 @@ extern "C" int sage_merge_attn_states(float* o_acc, float* lse_acc, const void* 
   if (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
   const int64_t threads = rows * (D / 8);
   const dim3 grid((unsigned)((threads + 255) / 256));
+  launch_begin();
   if (o_dtype == SAGE_BF16)
     hipLaunchKernelGGL((merge_states_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, o_acc, lse_acc, (const uint16_t*)o_blk, lse_blk, rows, D);
   else
@@ -128,6 +129,7 @@ extern "C" int sage_merge_attn_states_multi(const void* const* o_blks, const flo
   if (!aligned16(o_out)) return SAGE_ERR_INVALID_ARGUMENT;
   const int64_t threads = rows * (D / 8);
   const dim3 grid((unsigned)((threads + 255) / 256));
+  launch_begin();
   if (o_dtype == SAGE_BF16)
     hipLaunchKernelGGL((merge_many_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D);
   else
@@ -138,6 +140,7 @@ extern "C" int sage_merge_attn_states_multi(const void* const* o_blks, const flo
 extern "C" int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out, int64_t n,
                                sage_stream_t stream) {
   if (!lse2 || !lse_out || n <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  launch_begin();
   hipLaunchKernelGGL(finish_lse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lse2, corr, sm_scale, lse_out, n);
   return launch_status();
 }

@@ -272,6 +272,7 @@ extern "C" int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N,
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
   const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
   hipStream_t st = (hipStream_t)stream;
+  launch_begin();
   dim3 grid(S, H, B);
   const uint16_t* kp = (const uint16_t*)k->data;
   float* ws = (float*)workspace;
@@ -316,6 +317,7 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   p.warp_shift = warp == 16 ? 4 : warp == 32 ? 5 : warp == 64 ? 6 : 7;
   dim3 grid(nblk, H, B);
   hipStream_t st = (hipStream_t)stream;
+  launch_begin();
 #define LAUNCH(DD, BL, BF) hipLaunchKernelGGL((quant_qk_int8_kernel<DD, BL, BF>), grid, dim3(256), 0, st, p)
 #define BY_DT(DD, BL) do { if (dtype == SAGE_BF16) LAUNCH(DD, BL, true); else LAUNCH(DD, BL, false); } while (0)
   if (D == 64) { if (blk == 64) BY_DT(64, 64); else BY_DT(64, 128); }
@@ -350,6 +352,7 @@ extern "C" int sage_sub_mean_f16(const sage_tensor* v, int dtype, int B, int H, 
   const int RPP = 256 / (D / 8);
   dim3 grid((N + RPP - 1) / RPP, H, B);
   hipStream_t st = (hipStream_t)stream;
+  launch_begin();
   if (dtype == SAGE_BF16)
     hipLaunchKernelGGL((sub_mean_f16_kernel<true>), grid, dim3(256), 0, st, (const uint16_t*)v->data, v->stride_b, v->stride_h,
                        v->stride_n, (const uint16_t*)vm, (uint16_t*)out->data, out->stride_b, out->stride_h, out->stride_n, N, D);

@@ -80,3 +80,28 @@ def test_varlen_cross_lengths_bf16_int64():
         r = O.sdpa_fp32(q[cq[s]:cq[s + 1]].unsqueeze(0), k[ck[s]:ck[s + 1]].unsqueeze(0), v[ck[s]:ck[s + 1]].unsqueeze(0),
                         tensor_layout="NHD", sm_scale=D ** -0.5)[0]
         assert (o[cq[s]:cq[s + 1]].cpu().float() - r).abs().max() < 0.08
+
+
+@pytest.mark.gpu
+def test_varlen_sequence_without_keys_gives_zero_rows():
+    """A sequence that has queries but NO keys: the reference kernel stores zeros for its rows (the tile loop never runs,
+    acc = 0, l_i = 1; attn_qk_int8_block_varlen.py:109-121).  The output buffer is pre-filled with NaN bit patterns here
+    (through the caching allocator) so that unwritten rows would show."""
+    import sageattention_amd as sa
+    from oracle import sage_oracle as O
+    torch.manual_seed(9)
+    lq, lk = [70, 200, 33], [128, 0, 40]
+    cq = torch.tensor([0] + list(np.cumsum(lq)), dtype=torch.int32)
+    ck = torch.tensor([0] + list(np.cumsum(lk)), dtype=torch.int32)
+    H, D = 4, 64
+    q = torch.randn(sum(lq), H, D, dtype=torch.float16)
+    k = torch.randn(sum(lk), H, D, dtype=torch.float16)
+    v = torch.randn(sum(lk), H, D, dtype=torch.float16)
+    poison = torch.full((sum(lq), H, D), float("nan"), dtype=torch.float16, device="cuda")
+    del poison  # its block is the next allocation of that size: the operator's output
+    o = sa.sageattn_varlen(q.cuda(), k.cuda(), v.cuda(), cq.cuda(), ck.cuda(), max(lq), max(lk))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    assert (o[cq[1]:cq[2]] == 0).all()
+    oo = O.sageattn_varlen_oracle(q, k, v, cq, ck)
+    assert ((o.cpu().float() - oo.float()).abs() <= 4 * 2.0 ** -10 * oo.float().abs().clamp(min=0.25)).all()
