@@ -91,7 +91,8 @@ def main():
     ap.add_argument("--no-fa2", action="store_true")
     ap.add_argument("--pv", default=None, choices=["fp16", "fp8"], help="override the PV precision of the workload")
     ap.add_argument("--causal", default=None, type=int, choices=[0, 1], help="override the workload's causal flag")
-    ap.add_argument("--schedule", default="direct", choices=["direct", "ring"], help="N>1: KV exchange schedule")
+    ap.add_argument("--schedule", default="gather", choices=["gather", "direct", "ring"],
+                    help="N>1: KV exchange schedule (gather: whole-sequence smoothing, one launch over all remote shards)")
     ap.add_argument("--sp", default="ring", choices=["ring", "ulysses"], help="N>1: sequence-parallel scheme (ring = "
                     "BASELINE configs[4]; ulysses = head-parallel all-to-all, SURVEY 8 f4)")
     ap.add_argument("--causal-layout", default="zigzag", choices=["zigzag", "contiguous"],

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SAGEATTN_HIP_ABI_VERSION 1
+#define SAGEATTN_HIP_ABI_VERSION 2
 
 typedef void* sage_stream_t; /* hipStream_t */
 
@@ -249,6 +249,75 @@ int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* 
 /* lse_out[i] = lse2[i]/log2(e) + (corr ? corr[i]*sm_scale : 0)   (core.py:651), n elements. */
 int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out,
                     int64_t n, sage_stream_t stream);
+
+/* ==== sequence-parallel building blocks (new: the reference has no parallelism code; its hook is
+ * return_lse, core.py:122-124, and its multi-GPU launcher delegates to xDiT, example/parallel_sageattn_cogvideo.py:40-52).
+ * With ONE smoothing mean and ONE V scale for the whole sequence (statistics exchanged first: a few KB), the quantized
+ * K/V shards of all ranks are exactly the operands of the unsharded operator, so a rank attends the gathered shards
+ * with plain launches of the attention kernel: no per-shard LSE corrections, no per-shard outputs.
+ * The exchange buffers are TILE-MAJOR: tile j (64 keys) of every (b, h_kv) is one contiguous block,
+ *   k8 [tiles][B][Hk][64][D] int8, v fp16 [tiles][B][Hk][64][D] / v fp8 [tiles][B][Hk][D][64], k_scale [tiles][B][Hk][4|1],
+ * so the tiles received from all ranks, stored one rank after the other, form one sequence for every head. ==== */
+
+/* KV tile layout of an attention call: distance between consecutive 64-key tiles of one (b, h_kv).
+ * k_tile_stride: int8 elements (= bytes) in k8; v_tile_stride: elements of v (fp16: 2 bytes each; fp8: bytes);
+ * 0 = dense (64 * stride_n; fp8: 64).  Within a tile rows keep the sage_tensor's stride_n.
+ * ks_stride_{b,h,tile}: floats between the k scales of consecutive batches / kv heads / 64-key tiles; all 0 = the dense
+ * [B,Hk,Gk] layout.  per_thread scales are read 16 B at a time: multiples of 4. */
+typedef struct sage_kv_layout {
+  int64_t k_tile_stride, v_tile_stride;
+  int64_t ks_stride_b, ks_stride_h, ks_stride_tile;
+} sage_kv_layout;
+
+/* sage_attn_qk_int8_pv_{f16,f8} on K/V operands in an explicit tile layout (non-causal or causal; no v_mean).
+ * The raw base-2 LSE is returned as there. */
+int sage_attn_qk_int8_pv_f16_kvtiles(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, int v_dtype,
+                                     const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                     const sage_kv_layout* kv_layout, float* lse, int B, int Hq, int Hk, int M, int N,
+                                     int D, int is_causal, int qk_gran, int blkq, int warpq, float sm_scale,
+                                     sage_stream_t stream);
+int sage_attn_qk_int8_pv_f8_kvtiles(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v_fp8,
+                                    const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                    const float* v_scale, const sage_kv_layout* kv_layout, float* lse, int B, int Hq,
+                                    int Hk, int M, int N, int D, int is_causal, int qk_gran, int blkq, int warpq,
+                                    float sm_scale, sage_stream_t stream);
+
+/* Per-channel statistics of a [B,H,N,D] fp16/bf16 tensor over its N rows: stats fp32 [B,H,3,D] = (max, min, sum),
+ * deterministic two-level reduction.  The local halves of `k.mean` (core.py:612) and of the per-channel amax of
+ * per_channel_fp8 (quant.py:225-322, fused.cu:316-427).  workspace: sage_seq_stats_workspace_bytes bytes. */
+size_t sage_seq_stats_workspace_bytes(int B, int H, int N, int D);
+int sage_seq_stats(const sage_tensor* x, int dtype, int B, int H, int N, int D, float* stats, void* workspace,
+                   sage_stream_t stream);
+
+/* Combine the statistics of `parts` sequence shards (k_stats / v_stats: fp32 [BH][3][D] per shard, shard p at
+ * + p*part_stride floats, e.g. an all-gather of sage_seq_stats results; v_stats may be NULL) into the operands of the
+ * quantizers:
+ *   km [BH][D] (dtype) = sum of sums / n_total                      (core.py:612 over the WHOLE sequence)
+ *   v_scale fp32 [BH][D] = max |v| / scale_max,  v_coef fp32 [BH][2][D] = (0, scale_max / max |v|)   (quant.py:228,318-321)
+ * Fixed summation order: every rank computes identical bits from the same gathered statistics. */
+int sage_kv_stats_reduce(const float* k_stats, const float* v_stats, int parts, int64_t part_stride, int BH, int D,
+                         int64_t n_total, int dtype, float scale_max, void* km, float* v_scale, float* v_coef,
+                         sage_stream_t stream);
+
+/* sage_quant_qk_int8 for K with tile-major results: out row r of (b,h) is written at
+ * out->data + b*stride_b + h*stride_h + (r/64)*out_tile_stride + (r%64)*stride_n, its scales at
+ * scale + b*scale_strides[0] + h*scale_strides[1] + (r/64)*scale_strides[2] (+ 0..3).  blk = 64. */
+int sage_quant_k_int8_kvtiles(const sage_tensor* k, int dtype, int B, int H, int N, int D, const void* mean,
+                              const sage_tensor* out, int64_t out_tile_stride, float* scale,
+                              const int64_t* scale_strides, int gran, int rounding, sage_stream_t stream);
+
+/* Second half of sage_quant_v_fp8 alone: v -> e4m3 with GIVEN coefficients v_coef [B,H,2,D] = (mean, scale_max/amax)
+ * (sage_kv_stats_reduce), token block t of (b,h) written at v_fp8->data + b*stride_b + h*stride_h + t*out_tile_stride
+ * (bytes; 0 = 64: the dense [B,H,D,Npad] layout), channel d at + d*stride_n. */
+int sage_quant_v_fp8_apply(const sage_tensor* v, int dtype, int B, int H, int N, int D, const sage_tensor* v_fp8,
+                           int64_t out_tile_stride, const float* v_coef, sage_stream_t stream);
+
+/* sage_merge_attn_states_multi for partial results that share one smoothing vector: the inputs' LSE are multiplied by
+ * lse_in_mult first (1/log2(e) for the raw base-2 LSE of the attention entry points) and
+ * lse_out = log(sum) + (corr ? corr*corr_mult : 0)   (core.py:651 applied once, after the merge). */
+int sage_merge_attn_states_multi_ex(const void* const* o_blks, const float* const* lse_blks, int count, int o_dtype,
+                                    void* o_out, float* lse_out, int64_t rows, int D, float lse_in_mult,
+                                    const float* corr, float corr_mult, sage_stream_t stream);
 
 #ifdef __cplusplus
 }

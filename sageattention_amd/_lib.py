@@ -21,7 +21,14 @@ class SageTensor(ctypes.Structure):
     _fields_ = [("data", c_void_p), ("stride_b", c_int64), ("stride_h", c_int64), ("stride_n", c_int64)]
 
 
+class KvLayout(ctypes.Structure):
+    """sage_kv_layout (include/sageattn_hip.h): tile strides of k8 / v and the strides of the k scales."""
+    _fields_ = [("k_tile_stride", c_int64), ("v_tile_stride", c_int64), ("ks_stride_b", c_int64),
+                ("ks_stride_h", c_int64), ("ks_stride_tile", c_int64)]
+
+
 _P = ctypes.POINTER(SageTensor)
+_PL = ctypes.POINTER(KvLayout)
 _lib = None
 
 # name -> (restype, argtypes); must list every symbol include/sageattn_hip.h declares
@@ -58,6 +65,21 @@ SIGNATURES = {
     "sage_merge_attn_states_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sage_finish_lse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sage_set_tuning": (c_int, [c_int, c_int]),
+    "sage_attn_qk_int8_pv_f16_kvtiles": (c_int, [_P, _P, _P, c_int, _P, c_int, c_void_p, c_void_p, _PL, c_void_p,
+                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_float, c_void_p]),
+    "sage_attn_qk_int8_pv_f8_kvtiles": (c_int, [_P, _P, _P, _P, c_int, c_void_p, c_void_p, c_void_p, _PL, c_void_p,
+                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_float, c_void_p]),
+    "sage_seq_stats_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sage_seq_stats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sage_kv_stats_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_int, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "sage_quant_k_int8_kvtiles": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_void_p, _P, c_int64, c_void_p,
+                                          ctypes.POINTER(c_int64), c_int, c_int, c_void_p]),
+    "sage_quant_v_fp8_apply": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int64, c_void_p, c_void_p]),
+    "sage_merge_attn_states_multi_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int,
+                                                c_float, c_void_p, c_float, c_void_p]),
 }
 
 

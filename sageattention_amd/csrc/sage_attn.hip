@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     if (__builtin_amdgcn_ballot_w64(quantize(false) && triton) != 0) (void)quantize(true);
     qsc = sc * p.logit_mult;
   }
-  const float* ksp = p.k_scale + ((int64_t)b * p.Hk + hk) * p.gk;
+  const float* ksp = p.k_scale + b * p.ks_b + hk * p.ks_h;
 
   // ---- tile range
   const int kv_end = CAUSAL ? min(N_, (qb + 1) * QB) : N_;
@@ -201,13 +201,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
   const int8_t* kg = p.k + k_boff + hk * p.ksh;
   const uint8_t* vg = p.v + (v_boff + hk * p.vsh) * (PV_FP8 ? 1 : 2);
-  const unsigned k_bytes = (unsigned)((int64_t)(N_ - 1) * p.ksn + D);
-  const unsigned v_bytes = PV_FP8 ? (unsigned)((int64_t)(D - 1) * p.vsn + ((N_ + 63) & ~63))
-                                  : (unsigned)(((int64_t)(N_ - 1) * p.vsn + D) * 2);
+  const int k_tile_stride = p.k_tile_bytes;  // bytes per 64 keys (dense: 64 rows)
+  const int v_tile_stride = p.v_tile_bytes;
+  // last valid byte + 1 of the (b, h_kv) slice: row N-1 = row (N-1)%64 of tile (N-1)/64 (dense layouts: (N-1)*stride_n)
+  const int last_t = (N_ - 1) >> 6, last_r = (N_ - 1) & 63;
+  const unsigned k_bytes = (unsigned)((int64_t)last_t * k_tile_stride + (int64_t)last_r * p.ksn + D);
+  const unsigned v_bytes = PV_FP8 ? (unsigned)((int64_t)last_t * v_tile_stride + (int64_t)(D - 1) * p.vsn + 64)
+                                  : (unsigned)((int64_t)last_t * v_tile_stride + ((int64_t)last_r * p.vsn + D) * 2);
   const v4i k_rsrc = make_rsrc(kg, k_bytes), v_rsrc_dma = make_rsrc(vg, v_bytes);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
-  const int k_tile_stride = 64 * (int)p.ksn;                          // bytes per 64 keys
-  const int v_tile_stride = PV_FP8 ? 64 : 128 * (int)p.vsn;
   // LDS-DMA (buffer_load ... lds): a wave instruction writes 64 x 16 B = 1 KiB of LDS LINEARLY (wave-uniform
   // base + 16*lane), so the bank swizzle of the tile image is applied to the per-lane SOURCE offset instead:
   // LDS chunk position c of a tile holds global chunk (row(c), pos(c) ^ swizzle(row)).  No VGPR staging, no
@@ -361,8 +363,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // (x*q + z*0 is exactly x*q) instead of two v_mov + v_cndmask per scale: SGPR operands feed the VALU directly.
   const float qsc_lo = hh ? 0.f : qsc, qsc_hi = hh ? qsc : 0.f;
   auto load_kscales = [&](const int j) __attribute__((always_inline)) -> float4 {
-    if constexpr (KTHREAD) return uniform_load4(ksp + j * 4);
-    else return make_float4(uniform_load1(ksp + j), 0.f, 0.f, 0.f);
+    if constexpr (KTHREAD) return uniform_load4(ksp + j * p.ks_t);
+    else return make_float4(uniform_load1(ksp + j * p.ks_t), 0.f, 0.f, 0.f);
   };
   auto scales_from = [&](const float4 kk, float& sc0, float& sc1) __attribute__((always_inline)) {
     if constexpr (KTHREAD) {
@@ -997,7 +999,8 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
                     const float* v_mean, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal, int qk_gran,
                     int blkq, int warpq, float sm_scale, int logit_mult_is_one, hipStream_t st,
                     const int* cu_q = nullptr, const int* cu_k = nullptr, int q_dtype = -1, const void* km = nullptr,
-                    const void* mask = nullptr, int mask_kind = 0, const int64_t* mask_strides = nullptr) {
+                    const void* mask = nullptr, int mask_kind = 0, const int64_t* mask_strides = nullptr,
+                    const sage_kv_layout* kvl = nullptr) {
   if (mask && (mask_kind < 1 || mask_kind > 3 || !mask_strides || is_causal || pv_fp8 || cu_q || v_dtype != SAGE_F16)) return SAGE_ERR_INVALID_ARGUMENT;
   const bool fusedq = q_dtype >= 0;  // q8 is then the fp16/bf16 query tensor
   if ((cu_q == nullptr) != (cu_k == nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
@@ -1020,11 +1023,28 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   if (qk_gran == SAGE_GRAN_PER_BLOCK) warpq = blkq;
   if ((warpq != 16 && warpq != 32 && warpq != 64 && warpq != 128) || blkq % warpq != 0) return SAGE_ERR_INVALID_ARGUMENT;
   if ((v_mean && !aligned16(v_mean)) || (v_scale && !aligned16(v_scale))) return SAGE_ERR_INVALID_ARGUMENT;
+  // KV tile layout: dense by default (a tile = 64 consecutive rows of the sage_tensor), explicit for tile-major buffers
+  const int64_t ntile = ((int64_t)N + 63) >> 6;
+  int64_t k_tile = 64 * k8->stride_n, v_tile = pv_fp8 ? 64 : 128 * v->stride_n;  // bytes
+  const int per_tile = qk_gran == SAGE_GRAN_PER_THREAD ? 4 : 1;
+  int64_t ks_h = ntile * per_tile, ks_b = ks_h * Hk, ks_t = per_tile;
+  bool tiled = false;
+  if (kvl) {
+    if (cu_q || mask || kvl->k_tile_stride < 0 || kvl->v_tile_stride < 0) return SAGE_ERR_INVALID_ARGUMENT;
+    if (kvl->k_tile_stride) { k_tile = kvl->k_tile_stride; tiled = true; }
+    if (kvl->v_tile_stride) { v_tile = pv_fp8 ? kvl->v_tile_stride : 2 * kvl->v_tile_stride; tiled = true; }
+    if (kvl->ks_stride_b || kvl->ks_stride_h || kvl->ks_stride_tile) {
+      if (kvl->ks_stride_tile < per_tile || kvl->ks_stride_h < 0 || kvl->ks_stride_b < 0) return SAGE_ERR_INVALID_ARGUMENT;
+      ks_b = kvl->ks_stride_b; ks_h = kvl->ks_stride_h; ks_t = kvl->ks_stride_tile;
+      if (per_tile == 4 && ((ks_b | ks_h | ks_t) & 3)) return SAGE_ERR_INVALID_ARGUMENT;  // 16-B scalar loads
+    }
+    if ((k_tile & 15) || (v_tile & 15)) return SAGE_ERR_INVALID_ARGUMENT;
+  }
   // the K/V slices of one (b, h_kv) are addressed with 32-bit buffer offsets
   const int64_t lim = (int64_t)1 << 31;
-  const int64_t npad = ((int64_t)N + 63) & ~63ll;
-  if ((int64_t)N * k8->stride_n + D >= lim) return SAGE_ERR_TOO_LARGE;
-  if (pv_fp8 ? ((int64_t)D * v->stride_n + npad >= lim) : (((int64_t)N * v->stride_n + D) * 2 >= lim)) return SAGE_ERR_TOO_LARGE;
+  if (ntile * k_tile + 64 * k8->stride_n + D >= lim) return SAGE_ERR_TOO_LARGE;
+  if (pv_fp8 ? (ntile * v_tile + (int64_t)D * v->stride_n + 64 >= lim) : (ntile * v_tile + (64 * v->stride_n + D) * 2 >= lim)) return SAGE_ERR_TOO_LARGE;
+  if (ks_t * ntile >= lim) return SAGE_ERR_TOO_LARGE;
   AttnParams p;
   p.q = (const int8_t*)q8->data; p.qsb = q8->stride_b; p.qsh = q8->stride_h; p.qsn = q8->stride_n;
   p.k = (const int8_t*)k8->data; p.ksb = k8->stride_b; p.ksh = k8->stride_h; p.ksn = k8->stride_n;
@@ -1042,11 +1062,13 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.cu_q = cu_q; p.cu_k = cu_k;
   p.mask = (const uint8_t*)mask; p.mask_kind = mask ? mask_kind : 0;
   p.msb = mask ? mask_strides[0] : 0; p.msh = mask ? mask_strides[1] : 0; p.msm = mask ? mask_strides[2] : 0; p.msn = mask ? mask_strides[3] : 0;
+  p.k_tile_bytes = (int)k_tile; p.v_tile_bytes = (int)v_tile; p.ks_b = ks_b; p.ks_h = ks_h; p.ks_t = (int)ks_t;
+  p.kv_tiled = tiled ? 1 : 0;
   p.q_f16 = fusedq ? (const uint16_t*)q8->data : nullptr;
   p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
   // 64-rows-per-wave kernel (sage_attn_w64.hip): D = 128, fp16 V, dense, int8 q
-  const bool w64_ok = D == 128 && !pv_fp8 && !vb && !cu_q && !mask && !fusedq && !g_nwaves_override;
+  const bool w64_ok = D == 128 && !pv_fp8 && !vb && !cu_q && !mask && !fusedq && !g_nwaves_override && !kvl;
   if (w64_ok && g_w64 > 0) return launch_attn_w64(p, D, is_causal, kthread, pv_fp8, st);
   // measured on MI355X: D=128 fp16 PV -> one 8-wave workgroup per CU (4-wave: -3 %); D=128 fp8 PV -> two 4-wave
   // workgroups per CU (+3.6 % non-causal, +5.7 % causal); D=64 (<= 168 VGPRs) -> 4-wave workgroups, 3 per CU
@@ -1133,4 +1155,26 @@ extern "C" int sage_attn_qk_int8_pv_f16_masked(const sage_tensor* q8, const sage
   return run_attn(q8, k8, v, false, v_dtype, o, o_dtype, q_scale, k_scale, nullptr, nullptr, lse, B, Hq, Hk, M, N, D, 0, qk_gran,
                   blkq, warpq, sm_scale, logit_mult_is_one, (hipStream_t)stream, nullptr, nullptr, -1, nullptr, attn_mask,
                   mask_kind, mask_strides);
+}
+
+extern "C" int sage_attn_qk_int8_pv_f16_kvtiles(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, int v_dtype,
+                                                const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                                const sage_kv_layout* kv_layout, float* lse, int B, int Hq, int Hk, int M,
+                                                int N, int D, int is_causal, int qk_gran, int blkq, int warpq, float sm_scale,
+                                                sage_stream_t stream) {
+  if (!kv_layout) return SAGE_ERR_INVALID_ARGUMENT;
+  return run_attn(q8, k8, v, false, v_dtype, o, o_dtype, q_scale, k_scale, nullptr, nullptr, lse, B, Hq, Hk, M, N, D, is_causal,
+                  qk_gran, blkq, warpq, sm_scale, 0, (hipStream_t)stream, nullptr, nullptr, -1, nullptr, nullptr, 0, nullptr,
+                  kv_layout);
+}
+
+extern "C" int sage_attn_qk_int8_pv_f8_kvtiles(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v_fp8,
+                                               const sage_tensor* o, int o_dtype, const float* q_scale, const float* k_scale,
+                                               const float* v_scale, const sage_kv_layout* kv_layout, float* lse, int B,
+                                               int Hq, int Hk, int M, int N, int D, int is_causal, int qk_gran, int blkq,
+                                               int warpq, float sm_scale, sage_stream_t stream) {
+  if (!kv_layout) return SAGE_ERR_INVALID_ARGUMENT;
+  return run_attn(q8, k8, v_fp8, true, SAGE_F16, o, o_dtype, q_scale, k_scale, v_scale, nullptr, lse, B, Hq, Hk, M, N, D,
+                  is_causal, qk_gran, blkq, warpq, sm_scale, 0, (hipStream_t)stream, nullptr, nullptr, -1, nullptr, nullptr, 0,
+                  nullptr, kv_layout);
 }

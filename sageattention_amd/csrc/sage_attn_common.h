@@ -35,6 +35,14 @@ struct AttnParams {
   const uint8_t* mask;
   int64_t msb, msh, msm, msn;
   int mask_kind;
+  // KV tile layout (sage_kv_layout, include/sageattn_hip.h): byte distance between consecutive 64-key tiles of one
+  // (b, h_kv) in k8 and in v (always set by run_attn; the dense defaults are 64 rows), and the strides of k_scale
+  // (floats) per batch, kv head and 64-key tile.  Sequence-parallel exchange buffers are tile-major: tile j of every
+  // (b, h) is a contiguous block and the tiles of all ranks form one sequence.
+  int k_tile_bytes, v_tile_bytes;
+  int64_t ks_b, ks_h;
+  int ks_t;
+  int kv_tiled;  // non-default tile strides
 };
 
 // v_max_f32 on values that are never signalling NaNs: fmaxf() makes hipcc canonicalise both operands first

@@ -80,7 +80,7 @@ template <int D, bool BF16>
 __global__ __launch_bounds__(256) void v_quant_transpose_kernel(const uint16_t* __restrict__ v, int64_t sb, int64_t sh,
                                                                 int64_t sn, int N, const float* __restrict__ coef,
                                                                 uint8_t* __restrict__ out, int64_t ob, int64_t oh,
-                                                                int64_t od) {
+                                                                int64_t od, int64_t o_tile) {
   constexpr int TPR = D / 8, RPP = 256 / TPR, NP = 64 / RPP;
   const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
@@ -115,7 +115,48 @@ __global__ __launch_bounds__(256) void v_quant_transpose_kernel(const uint16_t* 
   for (int c = threadIdx.x; c < D * 4; c += 256) {
     const int d = c >> 2, ch = c & 3;
     const uint4 u = *reinterpret_cast<const uint4*>(&tile[d][ch * 16]);
-    *reinterpret_cast<uint4*>(out + b * ob + h * oh + (int64_t)d * od + blk * 64 + ch * 16) = u;
+    *reinterpret_cast<uint4*>(out + b * ob + h * oh + (int64_t)d * od + blk * o_tile + ch * 16) = u;
+  }
+}
+
+// raw per-channel statistics (max, min, sum) of one tensor: second level of v_stats_partial_kernel
+__global__ void seq_stats_final_kernel(const float* __restrict__ part, int S, int D, float* __restrict__ stats) {
+  const int64_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  float a = -1000000.0f, c = 1000000.0f, e = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* q = part + ((bh * S + s) * 3) * D + d;
+    a = fmaxf(a, q[0]); c = fminf(c, q[D]); e += q[2 * D];
+  }
+  float* o = stats + bh * 3 * D + d;
+  o[0] = a; o[D] = c; o[2 * D] = e;
+}
+
+// statistics of `parts` shards -> km (whole-sequence mean, storage dtype), v_scale, v_coef; fixed order over the shards
+template <bool BF16>
+__global__ void kv_stats_reduce_kernel(const float* __restrict__ ks, const float* __restrict__ vs, int parts,
+                                       int64_t part_stride, int BH, int D,
+                                       float n_total, float scale_max, uint16_t* __restrict__ km, float* __restrict__ v_scale,
+                                       float* __restrict__ v_coef) {
+  const int64_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  if (ks && km) {
+    float sum = 0.f;
+    for (int p = 0; p < parts; ++p) sum += ks[p * part_stride + (bh * 3 + 2) * D + d];
+    km[bh * D + d] = f32_to_elem_bits<BF16>(sum / n_total);
+  }
+  if (vs) {
+    float a = -1000000.0f, c = 1000000.0f;
+    for (int p = 0; p < parts; ++p) {
+      const float* q = vs + p * part_stride + (bh * 3) * D + d;
+      a = fmaxf(a, q[0]); c = fminf(c, q[D]);
+    }
+    const float amax = fmaxf(fabsf(a), fabsf(c));
+    v_scale[bh * D + d] = amax / scale_max;
+    v_coef[(bh * 2) * D + d] = 0.f;
+    v_coef[(bh * 2 + 1) * D + d] = scale_max / amax;
   }
 }
 
@@ -146,13 +187,79 @@ extern "C" int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, i
 #define L1(DD, BF) hipLaunchKernelGGL((v_stats_partial_kernel<DD, BF>), g1, dim3(256), 0, st, vp, v->stride_b, v->stride_h, v->stride_n, N, part, S)
 #define L2(DD, BF)                                                                                                    \
   hipLaunchKernelGGL((v_quant_transpose_kernel<DD, BF>), g2, dim3(256), 0, st, vp, v->stride_b, v->stride_h, v->stride_n, N, \
-                     coef, (uint8_t*)v_fp8->data, v_fp8->stride_b, v_fp8->stride_h, v_fp8->stride_n)
+                     coef, (uint8_t*)v_fp8->data, v_fp8->stride_b, v_fp8->stride_h, v_fp8->stride_n, (int64_t)64)
   const bool bf = dtype == SAGE_BF16;
   if (D == 64) { if (bf) L1(64, true); else L1(64, false); } else { if (bf) L1(128, true); else L1(128, false); }
   hipLaunchKernelGGL(v_stats_final_kernel, dim3(B * H), dim3(128), 0, st, part, S, D, N, scale_max, v_mean ? 1 : 0, v_scale,
                      v_mean, coef);
   if (D == 64) { if (bf) L2(64, true); else L2(64, false); } else { if (bf) L2(128, true); else L2(128, false); }
 #undef L1
+#undef L2
+  return launch_status();
+}
+
+extern "C" size_t sage_seq_stats_workspace_bytes(int B, int H, int N, int D) {
+  const size_t S = (size_t)(N + VQ_ROWS - 1) / VQ_ROWS;
+  return (size_t)B * H * S * 3 * D * sizeof(float);
+}
+
+extern "C" int sage_seq_stats(const sage_tensor* x, int dtype, int B, int H, int N, int D, float* stats, void* workspace,
+                              sage_stream_t stream) {
+  if (!x || !x->data || !aligned16(x->data) || x->stride_b % 8 || x->stride_h % 8 || x->stride_n % 8) return SAGE_ERR_INVALID_ARGUMENT;
+  if (!stats || !workspace || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int S = (N + VQ_ROWS - 1) / VQ_ROWS;
+  float* part = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  launch_begin();
+  const uint16_t* xp = (const uint16_t*)x->data;
+  const dim3 g1(S, H, B);
+  // rows in [N, ceil16(N)) would count as zeros in v_stats_partial_kernel (the reference's padded amax, fused.cu:335):
+  // harmless for max|x| and for the sum
+#define L1(DD, BF) hipLaunchKernelGGL((v_stats_partial_kernel<DD, BF>), g1, dim3(256), 0, st, xp, x->stride_b, x->stride_h, x->stride_n, N, part, S)
+  const bool bf = dtype == SAGE_BF16;
+  if (D == 64) { if (bf) L1(64, true); else L1(64, false); } else { if (bf) L1(128, true); else L1(128, false); }
+#undef L1
+  hipLaunchKernelGGL(seq_stats_final_kernel, dim3(B * H), dim3(128), 0, st, part, S, D, stats);
+  return launch_status();
+}
+
+extern "C" int sage_kv_stats_reduce(const float* k_stats, const float* v_stats, int parts, int64_t part_stride, int BH, int D, int64_t n_total,
+                                    int dtype, float scale_max, void* km, float* v_scale, float* v_coef, sage_stream_t stream) {
+  if ((!k_stats && !v_stats) || parts <= 0 || BH <= 0 || n_total <= 0 || part_stride < (int64_t)BH * 3 * D) return SAGE_ERR_INVALID_ARGUMENT;
+  if ((k_stats != nullptr) != (km != nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (v_stats && (!v_scale || !v_coef || !(scale_max > 0.f))) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  launch_begin();
+  if (dtype == SAGE_BF16)
+    hipLaunchKernelGGL((kv_stats_reduce_kernel<true>), dim3(BH), dim3(128), 0, (hipStream_t)stream, k_stats, v_stats, parts, part_stride, BH,
+                       D, (float)n_total, scale_max, (uint16_t*)km, v_scale, v_coef);
+  else
+    hipLaunchKernelGGL((kv_stats_reduce_kernel<false>), dim3(BH), dim3(128), 0, (hipStream_t)stream, k_stats, v_stats, parts, part_stride, BH,
+                       D, (float)n_total, scale_max, (uint16_t*)km, v_scale, v_coef);
+  return launch_status();
+}
+
+extern "C" int sage_quant_v_fp8_apply(const sage_tensor* v, int dtype, int B, int H, int N, int D, const sage_tensor* v_fp8,
+                                      int64_t out_tile_stride, const float* v_coef, sage_stream_t stream) {
+  if (!v || !v->data || !aligned16(v->data) || v->stride_b % 8 || v->stride_h % 8 || v->stride_n % 8) return SAGE_ERR_INVALID_ARGUMENT;
+  if (!v_fp8 || !v_fp8->data || !aligned16(v_fp8->data) || v_fp8->stride_b % 16 || v_fp8->stride_h % 16 || v_fp8->stride_n % 16)
+    return SAGE_ERR_INVALID_ARGUMENT;
+  if (!v_coef || B <= 0 || H <= 0 || N <= 0 || out_tile_stride < 0 || (out_tile_stride & 15)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int64_t o_tile = out_tile_stride ? out_tile_stride : 64;
+  hipStream_t st = (hipStream_t)stream;
+  launch_begin();
+  const uint16_t* vp = (const uint16_t*)v->data;
+  const dim3 g2((N + 63) / 64, H, B);
+#define L2(DD, BF)                                                                                                    \
+  hipLaunchKernelGGL((v_quant_transpose_kernel<DD, BF>), g2, dim3(256), 0, st, vp, v->stride_b, v->stride_h, v->stride_n, N, \
+                     v_coef, (uint8_t*)v_fp8->data, v_fp8->stride_b, v_fp8->stride_h, v_fp8->stride_n, o_tile)
+  const bool bf = dtype == SAGE_BF16;
+  if (D == 64) { if (bf) L2(64, true); else L2(64, false); } else { if (bf) L2(128, true); else L2(128, false); }
 #undef L2
   return launch_status();
 }

@@ -42,18 +42,20 @@ struct MergeMany {
 };
 template <bool BF16>
 __global__ __launch_bounds__(256) void merge_many_kernel(const MergeMany m, uint16_t* __restrict__ o_out,
-                                                         float* __restrict__ lse_out, int64_t rows, int D) {
+                                                         float* __restrict__ lse_out, int64_t rows, int D,
+                                                         const float in_mult, const float* __restrict__ corr,
+                                                         const float corr_mult) {
   const int tpr = D / 8;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = gid / tpr;
   const int c = (int)(gid % tpr);
   if (row >= rows) return;
   float mx = -INFINITY;
-  for (int i = 0; i < m.count; ++i) mx = fmaxf(mx, m.lse[i][row]);
+  for (int i = 0; i < m.count; ++i) mx = fmaxf(mx, m.lse[i][row] * in_mult);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float sum = 0.f;
   for (int i = 0; i < m.count; ++i) {  // fixed order: deterministic
-    const float l = m.lse[i][row];
+    const float l = m.lse[i][row] * in_mult;
     if (l == -INFINITY) continue;       // empty block (e.g. fully masked): weight 0, its o may be anything
     const float w = __expf(l - mx);
     sum += w;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void merge_many_kernel(const MergeMany m, uint
   for (int j = 0; j < 4; ++j)
     w[j] = (uint32_t)f32_to_elem_bits<BF16>(acc[2 * j] * inv) | ((uint32_t)f32_to_elem_bits<BF16>(acc[2 * j + 1] * inv) << 16);
   *reinterpret_cast<uint4*>(o_out + row * D + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-  if (c == 0 && lse_out) lse_out[row] = sum > 0.f ? mx + __logf(sum) : -INFINITY;
+  if (c == 0 && lse_out) lse_out[row] = (sum > 0.f ? mx + __logf(sum) : -INFINITY) + (corr ? corr[row] * corr_mult : 0.f);
 }
 
 __global__ __launch_bounds__(256) void finish_lse_kernel(const float* __restrict__ lse2, const float* __restrict__ corr,
@@ -113,8 +115,10 @@ extern "C" int sage_merge_attn_states(float* o_acc, float* lse_acc, const void* 
   return launch_status();
 }
 
-extern "C" int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* lse_blks, int count, int o_dtype,
-                                           void* o_out, float* lse_out, int64_t rows, int D, sage_stream_t stream) {
+extern "C" int sage_merge_attn_states_multi_ex(const void* const* o_blks, const float* const* lse_blks, int count, int o_dtype,
+                                               void* o_out, float* lse_out, int64_t rows, int D, float lse_in_mult,
+                                               const float* corr, float corr_mult, sage_stream_t stream) {
+  if (!(lse_in_mult > 0.f)) return SAGE_ERR_INVALID_ARGUMENT;
   if (!o_blks || !lse_blks || !o_out || count <= 0 || count > SAGE_MERGE_MAX || rows <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (o_dtype != SAGE_F16 && o_dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
@@ -131,10 +135,17 @@ extern "C" int sage_merge_attn_states_multi(const void* const* o_blks, const flo
   const dim3 grid((unsigned)((threads + 255) / 256));
   launch_begin();
   if (o_dtype == SAGE_BF16)
-    hipLaunchKernelGGL((merge_many_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D);
+    hipLaunchKernelGGL((merge_many_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D,
+                       lse_in_mult, corr, corr_mult);
   else
-    hipLaunchKernelGGL((merge_many_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D);
+    hipLaunchKernelGGL((merge_many_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D,
+                       lse_in_mult, corr, corr_mult);
   return launch_status();
+}
+
+extern "C" int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* lse_blks, int count, int o_dtype,
+                                           void* o_out, float* lse_out, int64_t rows, int D, sage_stream_t stream) {
+  return sage_merge_attn_states_multi_ex(o_blks, lse_blks, count, o_dtype, o_out, lse_out, rows, D, 1.0f, nullptr, 0.f, stream);
 }
 
 extern "C" int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out, int64_t n,

@@ -77,6 +77,9 @@ struct QuantParams {
   float mult;
   int rounding;
   const int* cu;  // varlen: sequence b = rows [cu[b], cu[b+1]) of the packed tensor (stride_b unused); N = max length
+  // result layout: rows of block `blk` start at blk * o_blk (elements; dense: BLK * osn); scales of (b, h, blk) at
+  // b*ss_b + h*ss_h + blk*ss_blk (floats; dense: [B,H,G])
+  int64_t o_blk, ss_b, ss_h, ss_blk;
 };
 
 __device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp_shift) {
@@ -174,10 +177,10 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   if (threadIdx.x < groups_per_blk) {
     const float a = __uint_as_float(gmax[threadIdx.x]);
     const float sc = (p.rounding == SAGE_ROUND_TRITON) ? a / 127.f + eps : fmaxf(a, 0.0000001f) / 127.f;
-    p.scale[((int64_t)b * H + h) * p.G + blk * groups_per_blk + threadIdx.x] = sc;
+    p.scale[b * p.ss_b + h * p.ss_h + blk * p.ss_blk + threadIdx.x] = sc;
   }
 
-  int8_t* obase = p.out + o_boff + h * p.osh + tc * 8;
+  int8_t* obase = p.out + o_boff + h * p.osh + blk * p.o_blk + tc * 8;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int lr = i * RPP + tr;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
       w0 |= (uint32_t)(min(max(q[j], -128), 127) & 0xff) << (8 * j);
       w1 |= (uint32_t)(min(max(q[4 + j], -128), 127) & 0xff) << (8 * j);
     }
-    if (row < N_) *reinterpret_cast<uint2*>(obase + (int64_t)row * p.osn) = make_uint2(w0, w1);
+    if (row < N_) *reinterpret_cast<uint2*>(obase + (int64_t)lr * p.osn) = make_uint2(w0, w1);
   }
 }
 
@@ -292,7 +295,7 @@ extern "C" int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N,
 static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int D, const void* mean,
                       const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
                       float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
-                      sage_stream_t stream, const int* cu) {
+                      sage_stream_t stream, const int* cu, int64_t out_blk_stride = 0, const int64_t* scale_strides = nullptr) {
   if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !scale || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
@@ -313,6 +316,11 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   p.out = (int8_t*)out->data; p.osb = out->stride_b; p.osh = out->stride_h; p.osn = out->stride_n;
   p.scale = scale; p.dot_vec = (const uint16_t*)lse_dot_vec; p.dot_out = lse_dot; p.dot_group = dot_group > 0 ? dot_group : 1;
   p.cu = cu;
+  p.o_blk = out_blk_stride ? out_blk_stride : (int64_t)blk * out->stride_n;
+  p.ss_b = scale_strides ? scale_strides[0] : (int64_t)H * nblk * gpb;
+  p.ss_h = scale_strides ? scale_strides[1] : (int64_t)nblk * gpb;
+  p.ss_blk = scale_strides ? scale_strides[2] : gpb;
+  if (out_blk_stride < 0 || (out_blk_stride & 7) || p.ss_blk < gpb) return SAGE_ERR_INVALID_ARGUMENT;
   p.N = N; p.G = nblk * gpb; p.gran = gran; p.is_key = is_key ? 1 : 0; p.warp = warp; p.mult = mult; p.rounding = rounding;
   p.warp_shift = warp == 16 ? 4 : warp == 32 ? 5 : warp == 64 ? 6 : 7;
   dim3 grid(nblk, H, B);
@@ -360,4 +368,13 @@ extern "C" int sage_sub_mean_f16(const sage_tensor* v, int dtype, int B, int H, 
     hipLaunchKernelGGL((sub_mean_f16_kernel<false>), grid, dim3(256), 0, st, (const uint16_t*)v->data, v->stride_b, v->stride_h,
                        v->stride_n, (const uint16_t*)vm, (uint16_t*)out->data, out->stride_b, out->stride_h, out->stride_n, N, D);
   return launch_status();
+}
+
+extern "C" int sage_quant_k_int8_kvtiles(const sage_tensor* k, int dtype, int B, int H, int N, int D, const void* mean,
+                                         const sage_tensor* out, int64_t out_tile_stride, float* scale,
+                                         const int64_t* scale_strides, int gran, int rounding, sage_stream_t stream) {
+  if (!scale_strides || out_tile_stride <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (gran != SAGE_GRAN_PER_BLOCK && gran != SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;  // the K granularities
+  return quant_impl(k, dtype, B, H, N, D, mean, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr,
+                    out_tile_stride, scale_strides);
 }

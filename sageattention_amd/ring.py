@@ -22,7 +22,17 @@ the diagonal when b == a and not at all when b > a, so against the shard of rank
 -- two half-block products per step on EVERY rank.  Shards are quantized once, whole; half-blocks are row slices
 of the quantized tensors and of their scale vectors (the chunk length must be a multiple of 128 rows).
 
-Two exchange schedules, same arithmetic (results are bit-identical):
+Three exchange schedules.  "gather" (default) changes the arithmetic for the better, the other two are bit-identical to
+each other:
+  "gather" ONE smoothing mean and ONE V scale for the whole sequence: the ranks first exchange their per-channel
+           statistics (K column sums, V max/min: ~100 KB, one all-gather), so every rank quantizes its shard exactly as
+           the unsharded operator would.  Each rank quantizes STRAIGHT INTO its slot of a tile-major exchange buffer
+           (one record per 64-key tile: K int8 | V fp8/fp16 | k scales of all heads), posts that slot to all peers at
+           once (7 xGMI links in parallel), attends its own shard while the exchange is in flight and then all remote
+           shards with ONE more launch of the attention kernel over the gathered records (which form one sequence for
+           every head), and merges the two partial results once.  No per-shard LSE corrections (the single correction
+           q.km comes out of the Q quantizer in fp32), no staging copy, no per-shard outputs.  Non-causal and
+           causal/contiguous; the zigzag layout uses "direct".
   "ring"   P-1 rotation steps, each overlapped with one block of compute; one xGMI link per direction is busy.
   "direct" the 8 GPUs of an MI355X node are fully connected by xGMI (7 links per GPU), so every rank posts its shard to
            ALL peers at once (P-1 isend + P-1 irecv in one RCCL group), computes its local block meanwhile and then
@@ -31,6 +41,7 @@ Two exchange schedules, same arithmetic (results are bit-identical):
 At C5 (n = 8192 rows per rank, D = 128, 32 heads) one block is ~1.1 TFLOP (~0.85 ms) while a ring step moves ~100 MB
 over a single link (>1.3 ms): the ring would be communication bound, the direct schedule is not.  Default: "direct".
 """
+import ctypes
 from typing import Any, Optional
 
 import torch
@@ -40,7 +51,7 @@ from . import _lib as L
 from . import _qattn
 from .quant import _quant, k_mean, per_channel_fp8
 
-__all__ = ["ring_sageattn", "HipRingBackend", "zigzag_split", "zigzag_merge"]
+__all__ = ["ring_sageattn", "HipRingBackend", "HipGatherBackend", "zigzag_split", "zigzag_merge"]
 
 
 def zigzag_split(x: torch.Tensor, world: int, rank: int, dim: int = 2) -> torch.Tensor:
@@ -155,6 +166,158 @@ class HipRingBackend:
         return blocks[0]
 
 
+class HipGatherBackend:
+    """Device steps of the "gather" schedule, all through the C ABI (include/sageattn_hip.h, "sequence-parallel
+    building blocks").  Tests substitute a CPU backend with the same methods (tests/ring_cpu_backend.py)."""
+
+    def __init__(self, pv: str = "fp8", qk_quant_gran: str = "per_thread"):
+        assert pv in ("fp16", "fp8") and qk_quant_gran in ("per_warp", "per_thread")
+        self.pv, self.gran = pv, qk_quant_gran
+        self.code = L.GRAN_PER_THREAD if qk_quant_gran == "per_thread" else L.GRAN_PER_WARP
+        self.kcode = L.GRAN_PER_THREAD if qk_quant_gran == "per_thread" else L.GRAN_PER_BLOCK
+        self.rnd = L.ROUND_TRITON if qk_quant_gran == "per_thread" else L.ROUND_CUDA
+        self.pt = 4 if qk_quant_gran == "per_thread" else 1   # k scales per 64-key tile
+
+    # -- per-channel statistics of the local shard: fp32 [c][B*Hk][3][D], c = 1 (K) or 2 (K, V)
+    def stats(self, k, v):
+        B, Hk, n, D = k.shape
+        if n % 64:
+            raise ValueError("the gather schedule needs shard lengths that are a multiple of 64 rows")
+        lib, st = L.lib(), L.stream_ptr(k.device)
+        c = 2 if self.pv == "fp8" else 1
+        out = torch.empty((c, B * Hk, 3, D), dtype=torch.float32, device=k.device)
+        ws = torch.empty(max(1, lib.sage_seq_stats_workspace_bytes(B, Hk, n, D) // 4) * c, dtype=torch.float32, device=k.device)
+        for i, x in enumerate((k, v)[:c]):
+            L.check(lib.sage_seq_stats(L.desc(x, "HND"), L.dtype_code(x.dtype), B, Hk, n, D, out[i].data_ptr(),
+                                       ws[i * (ws.numel() // c):].data_ptr(), st), "sage_seq_stats")
+        return out
+
+    # -- record layout of the exchange buffer
+    def _layout(self, B, Hk, n, D):
+        BH = B * Hk
+        kb = BH * 64 * D
+        vb = kb * (2 if self.pv == "fp16" else 1)
+        sb = (BH * self.pt * 4 + 15) // 16 * 16
+        return BH, kb, vb, kb + vb + sb, n // 64
+
+    def setup(self, all_stats, world, k, v):
+        """Whole-sequence smoothing mean / V scale from the gathered statistics, then K and V of the local shard
+        quantized straight into slot 0 of the exchange buffer.  Returns the buffer, uint8 [world, slot_bytes]."""
+        B, Hk, n, D = k.shape
+        BH, kb, vb, R, T = self._layout(B, Hk, n, D)
+        lib, st, dev = L.lib(), L.stream_ptr(k.device), k.device
+        c = all_stats.shape[1]
+        km = torch.empty((B, Hk, D), dtype=k.dtype, device=dev)
+        fp8 = self.pv == "fp8"
+        v_scale = torch.empty((B, Hk, D), dtype=torch.float32, device=dev) if fp8 else None
+        v_coef = torch.empty((B, Hk, 2, D), dtype=torch.float32, device=dev) if fp8 else None
+        part = c * BH * 3 * D
+        L.check(lib.sage_kv_stats_reduce(all_stats.data_ptr(), all_stats[0, 1].data_ptr() if fp8 else None, world, part, BH, D,
+                                         n * world, L.dtype_code(k.dtype), 448.0, km.data_ptr(), L.ptr(v_scale), L.ptr(v_coef),
+                                         st), "sage_kv_stats_reduce")
+        G = torch.empty((world, T * R), dtype=torch.uint8, device=dev)
+        base = G.data_ptr()
+        strides = (ctypes.c_int64 * 3)(Hk * self.pt, self.pt, R // 4)
+        L.check(lib.sage_quant_k_int8_kvtiles(L.desc(k, "HND"), L.dtype_code(k.dtype), B, Hk, n, D, km.data_ptr(),
+                                              L.SageTensor(base, Hk * 64 * D, 64 * D, D), R, base + kb + vb, strides,
+                                              self.kcode, self.rnd, st), "sage_quant_k_int8_kvtiles")
+        if fp8:
+            L.check(lib.sage_quant_v_fp8_apply(L.desc(v, "HND"), L.dtype_code(v.dtype), B, Hk, n, D,
+                                               L.SageTensor(base + kb, Hk * D * 64, D * 64, 64), R, v_coef.data_ptr(), st),
+                    "sage_quant_v_fp8_apply")
+        else:  # fp16/bf16 V: one strided copy into the tile records (a send buffer must be contiguous anyway)
+            dst = torch.as_strided(G.view(v.dtype), (T, B, Hk, 64, D), (R // 2, Hk * 64 * D, 64 * D, D, 1), kb // 2)
+            dst.copy_(v.reshape(B, Hk, T, 64, D).permute(2, 0, 1, 3, 4))
+        self.km, self.v_scale, self.v_dtype = km, v_scale, v.dtype
+        self.geom = (B, Hk, n, D)
+        return G
+
+    def prepare_q(self, q, sm_scale, want_corr):
+        """Queries quantized once; the smooth-K correction q.km (fp32, core.py:613-617) falls out of the same pass."""
+        g = q.shape[1] // self.km.shape[1]
+        q8, qs, corr = _quant(q, "HND", self.code, False, 128, 32, 1.0, self.rnd,
+                              dot_vec=self.km if want_corr else None, dot_group=g)
+        return {"q": q, "q8": q8, "qs": qs, "sm_scale": sm_scale, "corr": corr}
+
+    def attend(self, qstate, G, pos0, npos, causal):
+        """One launch of the attention kernel over the records of slots [pos0, pos0+npos): (o, raw base-2 LSE)."""
+        B, Hk, n, D = self.geom
+        BH, kb, vb, R, T = self._layout(B, Hk, n, D)
+        q, q8, qs = qstate["q"], qstate["q8"], qstate["qs"]
+        Hq, M = q.shape[1], q.shape[2]
+        lib, st = L.lib(), L.stream_ptr(q.device)
+        base = G.data_ptr() + pos0 * T * R
+        o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        lse2 = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device)
+        k8 = L.SageTensor(base, Hk * 64 * D, 64 * D, D)
+        args = (B, Hq, Hk, M, npos * n, D, int(causal), self.code, 128, 32, float(qstate["sm_scale"]), st)
+        if self.pv == "fp8":
+            lay = L.KvLayout(R, R, Hk * self.pt, self.pt, R // 4)
+            L.check(lib.sage_attn_qk_int8_pv_f8_kvtiles(L.desc(q8, "HND"), k8, L.SageTensor(base + kb, Hk * D * 64, D * 64, 64),
+                                                         L.desc(o, "HND"), L.dtype_code(o.dtype), qs.data_ptr(), base + kb + vb,
+                                                         self.v_scale.data_ptr(), lay, lse2.data_ptr(), *args),
+                    "sage_attn_qk_int8_pv_f8_kvtiles")
+        else:
+            lay = L.KvLayout(R, R // 2, Hk * self.pt, self.pt, R // 4)
+            L.check(lib.sage_attn_qk_int8_pv_f16_kvtiles(L.desc(q8, "HND"), k8, L.SageTensor(base + kb, Hk * 64 * D, 64 * D, D),
+                                                          L.dtype_code(self.v_dtype), L.desc(o, "HND"), L.dtype_code(o.dtype),
+                                                          qs.data_ptr(), base + kb + vb, lay, lse2.data_ptr(), *args),
+                    "sage_attn_qk_int8_pv_f16_kvtiles")
+        return o, lse2
+
+    def merge(self, parts, qstate, want_lse):
+        """(o, lse): the partial results share one smoothing vector, so they merge on their raw LSE and the correction
+        (q.km)*sm_scale of core.py:651 is added once."""
+        lib, st = L.lib(), L.stream_ptr(parts[0][0].device)
+        corr, sm = qstate["corr"], float(qstate["sm_scale"])
+        if len(parts) == 1:
+            o, lse2 = parts[0]
+            if not want_lse:
+                return o, None
+            lse = torch.empty_like(lse2)
+            L.check(lib.sage_finish_lse(lse2.data_ptr(), L.ptr(corr), sm, lse.data_ptr(), lse2.numel(), st), "sage_finish_lse")
+            return o, lse
+        o0 = parts[0][0]
+        o = torch.empty(o0.shape, dtype=o0.dtype, device=o0.device)
+        lse = torch.empty(parts[0][1].shape, dtype=torch.float32, device=o0.device) if want_lse else None
+        op = (ctypes.c_void_p * len(parts))(*[b[0].data_ptr() for b in parts])
+        lp = (ctypes.c_void_p * len(parts))(*[b[1].data_ptr() for b in parts])
+        L.check(lib.sage_merge_attn_states_multi_ex(op, lp, len(parts), L.dtype_code(o0.dtype), o.data_ptr(), L.ptr(lse),
+                                                    parts[0][1].numel(), o0.shape[-1], 1.0 / 1.44269504,
+                                                    L.ptr(corr) if want_lse else None, sm, st),
+                "sage_merge_attn_states_multi_ex")
+        return o, lse
+
+
+def _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer):
+    """schedule="gather" (module docstring).  Slot p of a rank's exchange buffer holds the shard of rank (rank - p) mod P:
+    its own shard first, then the ranks before it -- exactly the shards a causal rank needs, contiguously."""
+    st = be.stats(k, v)
+    if world > 1:
+        flat = torch.empty(world * st.numel(), dtype=st.dtype, device=st.device)
+        dist.all_gather_into_tensor(flat, st.reshape(-1), group=group)
+        all_stats = flat.view((world,) + tuple(st.shape))
+    else:
+        all_stats = st.unsqueeze(0)
+    G = be.setup(all_stats, world, k, v)
+    qstate = be.prepare_q(q, sm_scale, return_lse)
+    nremote = (rank if is_causal else world - 1) if world > 1 else 0           # slots 1 .. nremote are used
+    ops = []
+    for p_ in range(1, world):
+        dst, src = (rank + p_) % world, (rank - p_) % world
+        if not (is_causal and dst < rank):      # rank dst attends our shard (its slot p_)
+            ops.append(dist.P2POp(dist.isend, G[0], peer(dst), group))
+        if p_ <= nremote:
+            ops.append(dist.P2POp(dist.irecv, G[p_], peer(src), group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    parts = [be.attend(qstate, G, 0, 1, is_causal)]       # own shard, while the exchange is in flight
+    for r in reqs:
+        r.wait()
+    if nremote:
+        parts.append(be.attend(qstate, G, 1, nremote, False))  # every remote shard in one launch
+    return be.merge(parts, qstate, return_lse)
+
+
 def _pack(parts):
     """One contiguous uint8 buffer holding every travelling tensor (16-B aligned slots) + the views into it."""
     names = sorted(parts)
@@ -186,7 +349,7 @@ def _views_like(buf, views):
 def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
                   sm_scale: Optional[float] = None, group: Optional[dist.ProcessGroup] = None, pv: str = "auto",
                   qk_quant_gran: str = "per_thread", return_lse: bool = False, backend: Any = None,
-                  schedule: str = "direct", causal_layout: str = "contiguous", **kwargs: Any):
+                  schedule: str = "gather", causal_layout: str = "contiguous", **kwargs: Any):
     """SageAttention over a sequence sharded across the ranks of ``group``.  Equal shard lengths; rank r holds rows
     [r*n, (r+1)*n) of q, k, v (``causal_layout="contiguous"``) or the zigzag rows ``zigzag_split(x, P, r)``
     (``"zigzag"``, balances causal work; chunk length n/2 must be a multiple of 128).  Same tensor conventions as
@@ -195,7 +358,7 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     elif tensor_layout != "HND":
         raise ValueError(f"Unknown tensor layout: {tensor_layout}")
-    if schedule not in ("ring", "direct"):
+    if schedule not in ("ring", "direct", "gather"):
         raise ValueError(f"Unknown schedule: {schedule}")
     if causal_layout not in ("contiguous", "zigzag"):
         raise ValueError(f"Unknown causal_layout: {causal_layout}")
@@ -212,10 +375,24 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
     if pv == "auto":  # the dispatcher's rule (core.dispatch_pv) on the WHOLE sequence: FP8 PV from a few thousand keys per row
         from .core import dispatch_pv
         pv = dispatch_pv(q, k, "HND", is_causal, n_kv=k.size(2) * world)
-    be = backend if backend is not None else HipRingBackend(pv, qk_quant_gran)
 
     def peer(r):  # group rank -> global rank for P2POp
         return dist.get_global_rank(group, r) if (world > 1 and group is not None) else r
+
+    if schedule == "gather":
+        gather_ok = (not zigzag and k.size(2) % 64 == 0 and q.size(0) == k.size(0)
+                     and (backend is None or hasattr(backend, "setup")))
+        if gather_ok and backend is None:  # 32-bit tile offsets span the whole gathered buffer of one launch
+            per_tile = k.size(0) * k.size(1) * 64 * D * (3 if pv == "fp16" else 2) + k.size(0) * k.size(1) * 16 + 16
+            gather_ok = per_tile * (k.size(2) // 64) * world < (1 << 31) - (1 << 22)
+        if gather_ok:
+            be = backend if backend is not None else HipGatherBackend(pv, qk_quant_gran)
+            o, lse = _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer)
+            if tensor_layout == "NHD":
+                o = o.transpose(1, 2)
+            return (o, lse) if return_lse else o
+        schedule = "direct"   # zigzag layout, ragged shards, very large batches: the per-shard path
+    be = backend if backend is not None else HipRingBackend(pv, qk_quant_gran)
 
     qstate = be.prepare_q(q, sm_scale)
     cur_buf, cur = _pack(be.prepare_kv(k, v))

@@ -64,3 +64,86 @@ class OracleRingBackend:
         w = torch.exp(lses - lse).nan_to_num(0.0)                        # blocks with lse = -inf weigh 0
         o = sum(b[0].float() * w[i].unsqueeze(-1) for i, b in enumerate(blocks))
         return o.to(blocks[0][0].dtype), lse
+
+
+class OracleGatherBackend:
+    """CPU stand-in for sageattention_amd.ring.HipGatherBackend (schedule "gather"): whole-sequence smoothing mean and
+    V scale from exchanged statistics, shards quantized into one byte slot each, gathered slots attended as ONE sequence.
+    Same method names and call order as the HIP backend; the slot is a plain concatenation of the tensors' bytes."""
+
+    def __init__(self, pv="fp8", qk_quant_gran="per_thread"):
+        self.pv, self.gran = pv, qk_quant_gran
+
+    def stats(self, k, v):
+        def one(x):
+            xf = x.float()
+            B, H, n, D = xf.shape
+            return torch.stack([xf.amax(2), xf.amin(2), xf.sum(2)], dim=2).reshape(B * H, 3, D)
+        return torch.stack([one(k), one(v)] if self.pv == "fp8" else [one(k)])
+
+    def setup(self, all_stats, world, k, v):
+        B, Hk, n, D = k.shape
+        ksum = torch.zeros(B * Hk, D)
+        for p in range(world):                       # fixed order, as sage_kv_stats_reduce
+            ksum = ksum + all_stats[p, 0, :, 2, :]
+        km = (ksum / float(n * world)).to(k.dtype).view(B, Hk, 1, D)
+        if self.gran == "per_thread":
+            gid, ng = O.gid_per_thread_k(n)
+            k8, ks = O.quant_int8_grouped(k, gid, ng, mean=km, rounding="triton", scale_eps=1e-7)
+        else:
+            gid, ng = O.gid_per_block(n, 64)
+            k8, ks = O.quant_int8_grouped(k, gid, ng, mean=km, rounding="cuda")
+        self.km = km.squeeze(2).contiguous()
+        parts = [k8.contiguous(), ks.contiguous()]
+        if self.pv == "fp8":
+            vmax = all_stats[:, 1, :, 0, :].amax(0).view(B, Hk, D)
+            vmin = all_stats[:, 1, :, 1, :].amin(0).view(B, Hk, D)
+            amax = torch.maximum(vmax.abs(), vmin.abs())
+            y = v.float().transpose(2, 3) * (O.FP8_E4M3_MAX / amax).unsqueeze(-1)        # quant.py:318-321 with the GLOBAL amax
+            parts.append(y.clamp(-O.FP8_E4M3_MAX, O.FP8_E4M3_MAX).to(torch.float8_e4m3fn).contiguous())
+            self.v_scale = amax / O.FP8_E4M3_MAX
+        else:
+            parts.append(v.contiguous())
+        self.meta = [(t.shape, t.dtype) for t in parts]
+        slot = torch.cat([t.view(torch.uint8).reshape(-1) for t in parts])
+        G = torch.zeros((world, slot.numel()), dtype=torch.uint8)
+        G[0] = slot
+        return G
+
+    def _unpack(self, slot):
+        out, off = [], 0
+        for shape, dt in self.meta:
+            nb = int(torch.tensor(shape).prod()) * torch.empty((), dtype=dt).element_size()
+            out.append(slot[off:off + nb].view(dt).view(shape))
+            off += nb
+        return out
+
+    def prepare_q(self, q, sm_scale, want_corr):
+        if self.gran == "per_thread":
+            gid, n = O.gid_per_thread_q(q.shape[2])
+            q8, qs = O.quant_int8_grouped(q, gid, n, rounding="triton", scale_eps=1e-7)
+        else:
+            gid, n = O.gid_per_warp_q(q.shape[2], 128, 32)
+            q8, qs = O.quant_int8_grouped(q, gid, n, rounding="cuda")
+        corr = O.lse_correction(q, self.km, "HND") if want_corr else None
+        return {"q": q, "q8": q8, "qs": qs, "sm_scale": sm_scale, "corr": corr}
+
+    def attend(self, qstate, G, pos0, npos, causal):
+        sl = [self._unpack(G[p]) for p in range(pos0, pos0 + npos)]
+        k8 = torch.cat([s[0] for s in sl], dim=2)
+        ks = torch.cat([s[1] for s in sl], dim=2)
+        v = torch.cat([s[2] for s in sl], dim=3 if self.pv == "fp8" else 2)
+        q, q8, qs, sm = qstate["q"], qstate["q8"], qstate["qs"], qstate["sm_scale"]
+        qrows = O.expand_q_scale(qs, q8.shape[2], self.gran)
+        kcols = O.expand_k_scale(ks, k8.shape[2], self.gran)
+        return O.attn_tile_loop(q8, k8, v, qrows, kcols, logit_mult=sm * O.LOG2E, is_causal=causal, pv=self.pv,
+                                v_scale=self.v_scale if self.pv == "fp8" else None, out_dtype=q.dtype)
+
+    def merge(self, parts, qstate, want_lse):
+        lses = torch.stack([b[1] for b in parts]) / O.LOG2E
+        lse = torch.logsumexp(lses, dim=0)
+        w = torch.exp(lses - lse).nan_to_num(0.0)
+        o = sum(b[0].float() * w[i].unsqueeze(-1) for i, b in enumerate(parts)).to(parts[0][0].dtype)
+        if not want_lse:
+            return o, None
+        return o, lse + qstate["corr"] * qstate["sm_scale"]

@@ -33,7 +33,7 @@ def test_binding_covers_header(built_lib):
     from sageattention_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
     l = _lib.lib()
-    assert l.sage_abi_version() == 1
+    assert l.sage_abi_version() == 2
     assert l.sage_target_arch() == b"gfx950"
     assert b"head_dim" in l.sage_status_string(-2)
 

@@ -138,3 +138,72 @@ def test_zigzag_causal_ring(tmp_path, world, pv, layout, schedule):
         assert torch.equal(o_ser, outs[r]["o"]), f"rank {r} output differs from the serial replay"
         assert torch.equal(torch.cat([mlo[1], mhi[1]], dim=2), outs[r]["lse"])
     assert len(set(work)) == 1, f"zigzag must balance the half-block products across ranks, got {work}"
+
+
+def _gather_worker(rank, world, port, cfg, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ring_cpu_backend import OracleGatherBackend
+    from sageattention_amd.ring import ring_sageattn
+    B, Hq, Hk, N, D, causal, pv, layout, gran = cfg
+    q, k, v = _inputs(B, Hq, Hk, N, D)
+    n = N // world
+    ql, kl, vl = (t[:, :, rank * n:(rank + 1) * n] for t in (q, k, v))
+    if layout == "NHD":
+        ql, kl, vl = (t.transpose(1, 2).contiguous() for t in (ql, kl, vl))
+    o, lse = ring_sageattn(ql, kl, vl, tensor_layout=layout, is_causal=causal, return_lse=True, pv=pv, qk_quant_gran=gran,
+                           backend=OracleGatherBackend(pv=pv, qk_quant_gran=gran), schedule="gather")
+    if layout == "NHD":
+        o = o.transpose(1, 2)
+    torch.save({"o": o.contiguous(), "lse": lse}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,causal,pv,layout,gran", [
+    (2, False, "fp8", "HND", "per_thread"), (2, True, "fp16", "NHD", "per_thread"), (3, True, "fp8", "HND", "per_warp"),
+    (4, False, "fp16", "HND", "per_thread"), (3, False, "fp8", "NHD", "per_thread")])
+def test_gather_schedule_matches_the_unsharded_operator(tmp_path, world, causal, pv, layout, gran):
+    """schedule="gather": the ranks exchange per-channel statistics, quantize their shards with the WHOLE sequence's
+    smoothing mean and V scale, exchange the quantized slots and attend the gathered slots as one sequence.  Checks:
+    (1) vs exact fp32 attention over the whole sequence (operator tolerances); (2) vs the UNSHARDED oracle operator on
+    the gathered tensors -- same quantized operands by construction, so only the key order (own shard first), the
+    two-way merge and the per-rank Q blocks differ: |do| <= 2e-3 (fp16 PV) / 3e-2 (fp8 PV: one e4m3 step of a weight),
+    LSE <= 1e-3; (3) protocol, exact: a serial replay of every rank's steps in one process is bit-identical."""
+    from oracle import sage_oracle as O
+    cfg = (1, 4, 2, 128 * world, 64, causal, pv, layout, gran)
+    mp.spawn(_gather_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world, join=True)
+    B, Hq, Hk, N, D = cfg[:5]
+    q, k, v = _inputs(B, Hq, Hk, N, D)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=True) for r in range(world)]
+    o = torch.cat([x["o"] for x in outs], dim=2).float()
+    lse = torch.cat([x["lse"] for x in outs], dim=2)
+    ref, ref_lse = O.sdpa_fp32(q, k, v, is_causal=causal, return_lse=True)
+    assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
+    assert (lse - ref_lse).abs().max() < 0.06
+    oo, ol = O.sageattn_oracle(q, k, v, is_causal=causal, qk_quant_gran=gran, pv=pv, return_lse=True)
+    assert (o - oo.float()).abs().max() < (2e-3 if pv == "fp16" else 3e-2)
+    assert (lse - ol).abs().max() < 1e-3
+
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ring_cpu_backend import OracleGatherBackend
+    n = N // world
+    bes = [OracleGatherBackend(pv=pv, qk_quant_gran=gran) for _ in range(world)]
+    shards = [(k[:, :, r * n:(r + 1) * n], v[:, :, r * n:(r + 1) * n]) for r in range(world)]
+    all_stats = torch.stack([bes[r].stats(*shards[r]) for r in range(world)])
+    Gs = [bes[r].setup(all_stats, world, *shards[r]) for r in range(world)]
+    for r in range(world):
+        for p in range(1, world):
+            Gs[r][p] = Gs[(r - p) % world][0]
+        qs = bes[r].prepare_q(q[:, :, r * n:(r + 1) * n], D ** -0.5, True)
+        parts = [bes[r].attend(qs, Gs[r], 0, 1, causal)]
+        nrem = (r if causal else world - 1)
+        if nrem:
+            parts.append(bes[r].attend(qs, Gs[r], 1, nrem, False))
+        so, sl = bes[r].merge(parts, qs, True)
+        assert torch.equal(so, outs[r]["o"]), f"rank {r} output differs from the serial replay"
+        assert torch.equal(sl, outs[r]["lse"])

@@ -31,8 +31,8 @@ def _worker(rank, world, port, cfg, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sageattention_amd as sa
     from sageattention_amd.ring import zigzag_split
-    mode, N, D, causal, pv, schedule, layout = cfg
-    q, k, v = (t.cuda() for t in _inputs(N, D))
+    mode, N, D, causal, pv, schedule, layout = cfg[:7]
+    q, k, v = (t.cuda() for t in _inputs(N, D, *cfg[7:]))
     n = N // world
     if layout == "zigzag":
         ql, kl, vl = (zigzag_split(t, world, rank).contiguous() for t in (q, k, v))
@@ -53,13 +53,16 @@ def _worker(rank, world, port, cfg, out_dir):
     (3, ("ring", 1536, 64, True, "fp8", "ring", "contiguous")),
     (2, ("ring", 1024, 128, True, "fp16", "direct", "zigzag")),
     (2, ("ulysses", 768, 128, True, "fp8", "", "contiguous")),
+    (3, ("ring", 1536, 128, False, "fp8", "gather", "contiguous")),
+    (2, ("ring", 1024, 64, True, "fp16", "gather", "contiguous")),
+    (2, ("ring", 16384, 128, False, "fp8", "gather", "contiguous", 4, 2)),   # 8192 rows per rank, as C5
 ])
 def test_multi_process_sequence_parallel_on_one_gpu(tmp_path, world, cfg):
     from oracle import sage_oracle as O
     from sageattention_amd.ring import zigzag_merge
     mp.spawn(_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world, join=True)
-    mode, N, D, causal, pv, schedule, layout = cfg
-    q, k, v = _inputs(N, D)
+    mode, N, D, causal, pv, schedule, layout = cfg[:7]
+    q, k, v = _inputs(N, D, *cfg[7:])
     outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=True) for r in range(world)]
     if layout == "zigzag":
         o, lse = zigzag_merge([x["o"] for x in outs]).float(), zigzag_merge([x["lse"] for x in outs])
@@ -69,6 +72,12 @@ def test_multi_process_sequence_parallel_on_one_gpu(tmp_path, world, cfg):
     assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
     assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
     assert (lse - ref_lse).abs().max() < 0.06
+    if schedule == "gather":  # whole-sequence smoothing / V scale: the unsharded operator's operands (tests/test_gather_gpu.py)
+        import sageattention_amd as sa
+        fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+        o1, l1 = fn(q.cuda(), k.cuda(), v.cuda(), is_causal=causal, return_lse=True)
+        assert (o1.cpu().float() - o).abs().max() < (2e-3 if pv == "fp16" else 3e-2)
+        assert (l1.cpu() - lse).abs().max() < 1e-3
     if mode == "ulysses":  # the exchange only moves data: identical to the single-process operator
         import sageattention_amd as sa
         fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
