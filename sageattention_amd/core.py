@@ -16,7 +16,8 @@ import torch
 
 from . import _lib as L
 from . import _qattn
-from .quant import _quant, k_mean, per_channel_fp8, sub_mean
+from . import quant as _q
+from .quant import _quant, k_mean, k_smooth_quant, per_channel_fp8, sub_mean
 
 __all__ = ["sageattn", "sageattn_qk_int8_pv_fp16_cuda", "sageattn_qk_int8_pv_fp16_triton",
            "sageattn_qk_int8_pv_fp8_cuda", "sageattn_qk_int8_pv_fp8_cuda_sm90", "sageattn_varlen"]
@@ -93,11 +94,31 @@ FUSE_Q_QUANT = os.environ.get("SAGEATTN_FUSE_Q", "1") == "1"
 FUSE_Q_MAX_SEQ = 4096
 
 
-def _quant_k(k, km, tensor_layout, qk_quant_gran):
-    """K half of core.py:621-624."""
-    if qk_quant_gran == "per_warp":
-        return _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km, dense_heads=True)[:2]
-    return _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km, dense_heads=True)[:2]
+_K_QUANT = {"per_block": (L.GRAN_PER_BLOCK, L.ROUND_TRITON), "per_warp": (L.GRAN_PER_BLOCK, L.ROUND_CUDA),
+            "per_thread": (L.GRAN_PER_THREAD, L.ROUND_TRITON)}
+_Q_QUANT = {"per_block": (L.GRAN_PER_BLOCK, L.ROUND_TRITON), "per_warp": (L.GRAN_PER_WARP, L.ROUND_CUDA),
+            "per_thread": (L.GRAN_PER_THREAD, L.ROUND_TRITON)}
+
+
+def _prep_k(k, tensor_layout, qk_quant_gran, smooth_k):
+    """``km = k.mean(seq)`` (core.py:612) + the K half of the quantizer pairings of core.py:621-624 -> (k8, ks, km).
+    With smoothing this is ONE launch that reads K once (sage_k_prep); bit-identical to k_mean + quantizer."""
+    gran, rnd = _K_QUANT[qk_quant_gran]
+    if smooth_k and _q.SINGLE_PASS:
+        return k_smooth_quant(k, tensor_layout, gran, rnd)
+    km = k_mean(k, tensor_layout) if smooth_k else None
+    k8, ks, _ = _quant(k, tensor_layout, gran, True, 64, 64, 1.0, rnd, mean=km, dense_heads=True)
+    return k8, ks, km
+
+
+def _quant_q(q, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, want_lse_corr, Hq, Hk):
+    """Q half of core.py:621-624 (+ the LSE correction q.km of core.py:613-617 in the same pass) -> (q8, qs, corr)."""
+    gran, rnd = _Q_QUANT[qk_quant_gran]
+    dot_vec = km if (want_lse_corr and km is not None) else None
+    if qk_quant_gran == "per_block":  # triton path: sm_scale*log2e folded into Q (quant_per_block.py:84)
+        return _quant(q, tensor_layout, gran, False, 128, 128, sm_scale * 1.44269504, rnd, dot_vec=dot_vec,
+                      dot_group=Hq // Hk, dense_heads=True)
+    return _quant(q, tensor_layout, gran, False, 128, WARPQ, 1.0, rnd, dot_vec=dot_vec, dot_group=Hq // Hk, dense_heads=True)
 
 
 def _fused_attn(q, k8, ks, v, o, km, v_scale, v_mean, tensor_layout, is_causal, qk_quant_gran, warpq, sm_scale, return_lse,
@@ -135,18 +156,17 @@ def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smoot
             sm_scale = head_dim_og ** -0.5
         _, Hq, _, _ = L.dims(q, tensor_layout)
         _, Hk, _, _ = L.dims(k, tensor_layout)
-        km = k_mean(k, tensor_layout) if smooth_k else None
+        k8, ks, km = _prep_k(k, tensor_layout, qk_quant_gran, smooth_k)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         vm = None
         if smooth_v:
             v, vm = sub_mean(v, tensor_layout)
         if FUSE_Q_QUANT and qk_quant_gran != "per_block" and L.dims(q, tensor_layout)[2] <= FUSE_Q_MAX_SEQ:
-            k8, ks = _quant_k(k, km, tensor_layout, qk_quant_gran)
             lse = _fused_attn(q, k8, ks, v, o, km, None, vm, tensor_layout, is_causal, qk_quant_gran, WARPQ, sm_scale,
                               return_lse, False)
             o = o[..., :head_dim_og]
             return (o, lse) if return_lse else o
-        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, return_lse, Hq, Hk)
+        q8, qs, corr = _quant_q(q, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, return_lse, Hq, Hk)
         lse2 = _qattn._attn_f16(q8, k8, v, o, qs, ks, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
                                 _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse),
                                 logit_mult_is_one=(qk_quant_gran == "per_block"))
@@ -228,8 +248,8 @@ def sageattn_qk_int8_pv_fp16_triton(
             raise AssertionError(f"attn_mask shape {attn_mask.shape} cannot be broadcast to {(B, Hq, M, N)}")
         if v.dtype != torch.float16:
             v = v.to(torch.float16)  # core.py:289-290
-        km = k_mean(k, tensor_layout) if smooth_k else None
-        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, "per_block", sm_scale, 32, return_lse, Hq, Hk)
+        k8, ks, km = _prep_k(k, tensor_layout, "per_block", smooth_k)
+        q8, qs, corr = _quant_q(q, km, tensor_layout, "per_block", sm_scale, 32, return_lse, Hq, Hk)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         lse2 = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device) if return_lse else None
         kind = 1 if attn_mask.dtype == torch.bool else (2 if attn_mask.dtype == torch.float16 else 3)
@@ -276,16 +296,15 @@ def sageattn_qk_int8_pv_fp8_cuda(
             sm_scale = head_dim_og ** -0.5
         _, Hq, _, _ = L.dims(q, tensor_layout)
         _, Hk, _, _ = L.dims(k, tensor_layout)
-        km = k_mean(k, tensor_layout) if smooth_k else None
+        k8, ks, km = _prep_k(k, tensor_layout, qk_quant_gran, smooth_k)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         v8, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
         if FUSE_Q_QUANT and L.dims(q, tensor_layout)[2] <= FUSE_Q_MAX_SEQ:
-            k8, ks = _quant_k(k, km, tensor_layout, qk_quant_gran)
             lse = _fused_attn(q, k8, ks, v8, o, km, v_scale, vm, tensor_layout, is_causal, qk_quant_gran, 32, sm_scale,
                               return_lse, True)
             o = o[..., :head_dim_og]
             return (o, lse) if return_lse else o
-        q8, qs, k8, ks, corr = _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, 32, return_lse, Hq, Hk)
+        q8, qs, corr = _quant_q(q, km, tensor_layout, qk_quant_gran, sm_scale, 32, return_lse, Hq, Hk)
         lse2 = _qattn._attn_f8(q8, k8, v8, o, qs, ks, v_scale, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
                                _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse))
         o = o[..., :head_dim_og]

@@ -117,23 +117,16 @@ def test_c5_shape_rehearsal_on_one_gpu(causal):
     v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
     ranks = (0, 3, 7)
     res = _replay(sa, q, k, v, P, causal, "fp8", "per_thread", ranks=ranks)
+    # the unsharded operator on the whole sequence: same quantized operands by construction (one smoothing mean, one V
+    # scale); the key order (own shard first), the merge and the lazy-rescale history of a row differ
+    o_full, l_full = sa.sageattn_qk_int8_pv_fp8_cuda(q, k, v, is_causal=causal, return_lse=True)
     for r in ranks:
         rows = slice(r * n, (r + 1) * n)
         o, lse = res[r]
-        if causal:   # rank r sees keys [0, (r+1)*n): the operator on that prefix, bottom rows
-            o1, l1 = sa.sageattn_qk_int8_pv_fp8_cuda(q[:, :, :(r + 1) * n], k[:, :, :(r + 1) * n], v[:, :, :(r + 1) * n],
-                                                     is_causal=True, return_lse=True)
-            o1, l1 = o1[:, :, rows], l1[:, :, rows]
-            # NOTE: the prefix operator smooths/scales with the PREFIX statistics, the ring with the whole sequence's:
-            # different quantized operands -> compare at the operator tolerance vs exact attention instead (below)
-            tol_o, tol_l = 0.1, 0.05
-        else:
-            o1, l1 = sa.sageattn_qk_int8_pv_fp8_cuda(q[:, :, rows], k, v, return_lse=True)
-            tol_o, tol_l = 3e-2, 1e-3
         assert torch.isfinite(o).all() and torch.isfinite(lse).all()
-        assert (o.float() - o1.float()).abs().max() < tol_o, r
-        assert (lse - l1).abs().max() < tol_l, r
-        assert calc_diff(o.float().cpu(), o1.float().cpu()) < 2e-3
+        assert (o.float() - o_full[:, :, rows].float()).abs().max() < 3e-2, r
+        assert (lse - l_full[:, :, rows]).abs().max() < 1e-3, r
+        assert calc_diff(o.float().cpu(), o_full[:, :, rows].float().cpu()) < 2e-3   # outputs are ~1e-2 (64K random keys): fp8 P noise
     # oracle, one head of the last rank (exact fp32 attention of that head on the CPU)
     r, h = 7, 5
     rows = slice(r * n, (r + 1) * n)
