@@ -76,9 +76,7 @@ const char* sage_target_arch(void);
  * of the attention kernels, value in {0 = default, 4, 8}.  key SAGE_TUNE_W64: the 64-query-rows-per-wave
  * kernel (one wave per SIMD; head_dim 128, fp16 V), value in {0 = library default, 1 = use where it
  * applies, -1 = never}. */
-/* key SAGE_TUNE_PREP_POLL: polls a workgroup of sage_k_prep / sage_v_prep_fp8 spends waiting for the other chunks of
- * its (b,h) before it recomputes their statistics itself; 0 = default (65536), 1 = (tests) practically never wait. */
-typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0, SAGE_TUNE_W64 = 1, SAGE_TUNE_PREP_POLL = 2 } sage_tune_key;
+typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0, SAGE_TUNE_W64 = 1 } sage_tune_key;
 int sage_set_tuning(int key, int value);
 
 /* ---- K smoothing ---------------------------------------------------------------------------
@@ -251,22 +249,6 @@ int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* 
 /* lse_out[i] = lse2[i]/log2(e) + (corr ? corr[i]*sm_scale : 0)   (core.py:651), n elements. */
 int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out,
                     int64_t n, sage_stream_t stream);
-
-/* ---- single-pass pre-pass ----------------------------------------------------------
- * sage_k_prep = sage_k_mean + sage_quant_qk_int8(is_key, mean = that mean, blk 64) in ONE launch that reads K ONCE:
- * bit-identical km, int8 values and scales (gran SAGE_GRAN_PER_BLOCK or SAGE_GRAN_PER_THREAD; both roundings).
- * Replaces `k.mean` (core.py:612) + quant_per_block_int8_fuse_sub_mean_cuda (fused.cu:594-682) / the K half of
- * per_thread_int8 (triton/quant_per_thread.py:48-102, 162-163).  out / scale / km as in those functions.
- * sage_v_prep_fp8 = sage_quant_v_fp8 in ONE launch that reads V ONCE (bit-identical results).
- * The workgroups of one (b,h) exchange partial statistics through `workspace` (agent-scope release/acquire; bounded
- * polling with a self-help fallback, so completion never depends on dispatch order): sage_*_workspace_bytes bytes, 16-B
- * aligned, contents irrelevant on entry. */
-size_t sage_k_prep_workspace_bytes(int B, int H, int N, int D);
-int sage_k_prep(const sage_tensor* k, int dtype, int B, int H, int N, int D, const sage_tensor* out, float* scale,
-                void* km, int gran, int rounding, void* workspace, sage_stream_t stream);
-size_t sage_v_prep_fp8_workspace_bytes(int B, int H, int N, int D);
-int sage_v_prep_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D, const sage_tensor* v_fp8,
-                    float* v_scale, float* v_mean, float scale_max, void* workspace, sage_stream_t stream);
 
 /* ==== sequence-parallel building blocks (new: the reference has no parallelism code; its hook is
  * return_lse, core.py:122-124, and its multi-GPU launcher delegates to xDiT, example/parallel_sageattn_cogvideo.py:40-52).

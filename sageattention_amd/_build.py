@@ -17,7 +17,6 @@ SOURCES = [
     # K1 (sage_quant.hip) -- the tile loop spells its fmas out (__builtin_fmaf), so it is unaffected
     ("sage_attn.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ("sage_attn_w64.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
-    ("sage_prep.hip", ["-ffp-contract=off"]),
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
 ]

@@ -65,10 +65,6 @@ SIGNATURES = {
     "sage_merge_attn_states_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sage_finish_lse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sage_set_tuning": (c_int, [c_int, c_int]),
-    "sage_k_prep_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "sage_k_prep": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "sage_v_prep_fp8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "sage_v_prep_fp8": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "sage_attn_qk_int8_pv_f16_kvtiles": (c_int, [_P, _P, _P, c_int, _P, c_int, c_void_p, c_void_p, _PL, c_void_p,
                                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                  c_float, c_void_p]),

@@ -16,8 +16,7 @@ import torch
 
 from . import _lib as L
 from . import _qattn
-from . import quant as _q
-from .quant import _quant, k_mean, k_smooth_quant, per_channel_fp8, sub_mean
+from .quant import _quant, k_mean, per_channel_fp8, sub_mean
 
 __all__ = ["sageattn", "sageattn_qk_int8_pv_fp16_cuda", "sageattn_qk_int8_pv_fp16_triton",
            "sageattn_qk_int8_pv_fp8_cuda", "sageattn_qk_int8_pv_fp8_cuda_sm90", "sageattn_varlen"]
@@ -102,10 +101,10 @@ _Q_QUANT = {"per_block": (L.GRAN_PER_BLOCK, L.ROUND_TRITON), "per_warp": (L.GRAN
 
 def _prep_k(k, tensor_layout, qk_quant_gran, smooth_k):
     """``km = k.mean(seq)`` (core.py:612) + the K half of the quantizer pairings of core.py:621-624 -> (k8, ks, km).
-    With smoothing this is ONE launch that reads K once (sage_k_prep); bit-identical to k_mean + quantizer."""
+    Two passes over K in three launches on purpose: single-pass forms (workgroups of a head exchanging partial sums
+    inside one launch; one workgroup per head re-reading out of L2) were built and measured SLOWER on MI355X for every
+    shape from 2K keys up (pre-pass) -- K's second read is an L2 / Infinity-Cache hit anyway."""
     gran, rnd = _K_QUANT[qk_quant_gran]
-    if smooth_k and _q.SINGLE_PASS:
-        return k_smooth_quant(k, tensor_layout, gran, rnd)
     km = k_mean(k, tensor_layout) if smooth_k else None
     k8, ks, _ = _quant(k, tensor_layout, gran, True, 64, 64, 1.0, rnd, mean=km, dense_heads=True)
     return k8, ks, km

@@ -992,7 +992,6 @@ static bool t_ok(const sage_tensor* t, int align_elems) {
 
 int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
 int g_w64 = 0;              // SAGE_TUNE_W64: 0 = default choice, 1 = force the 64-rows-per-wave kernel where it applies, -1 = never
-extern int g_prep_poll_limit;  // sage_prep.hip
 
 // shared argument handling of the two attention entry points
 static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
@@ -1094,11 +1093,6 @@ extern "C" int sage_set_tuning(int key, int value) {
   if (key == SAGE_TUNE_W64) {
     if (value < -1 || value > 1) return SAGE_ERR_INVALID_ARGUMENT;
     g_w64 = value;
-    return SAGE_OK;
-  }
-  if (key == SAGE_TUNE_PREP_POLL) {
-    if (value < 0) return SAGE_ERR_INVALID_ARGUMENT;
-    g_prep_poll_limit = value;
     return SAGE_OK;
   }
   return SAGE_ERR_INVALID_ARGUMENT;

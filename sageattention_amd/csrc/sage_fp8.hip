@@ -63,9 +63,18 @@ __global__ void v_stats_final_kernel(const float* __restrict__ part, int S, int 
   const int d = threadIdx.x;
   if (d >= D) return;
   float a = -1000000.0f, c = 1000000.0f, e = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float* q = part + ((bh * S + s) * 3) * D + d;
-    a = fmaxf(a, q[0]); c = fminf(c, q[D]); e += q[2 * D];
+  // 8 chunks' partials in flight, combined in chunk order (a plain loop pays one memory round trip per chunk)
+  for (int s0 = 0; s0 < S; s0 += 8) {
+    float va[8], vc[8], ve[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = min(s0 + u, S - 1);
+      const float* q = part + ((bh * S + s) * 3) * D + d;
+      va[u] = q[0]; vc[u] = q[D]; ve[u] = q[2 * D];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < S) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); e += ve[u]; }
   }
   const int n16 = (N + 15) / 16 * 16;
   const float mean = smooth ? e / (float)n16 : 0.f;  // fused.cu:381: divides by the 16-padded token count
@@ -125,9 +134,17 @@ __global__ void seq_stats_final_kernel(const float* __restrict__ part, int S, in
   const int d = threadIdx.x;
   if (d >= D) return;
   float a = -1000000.0f, c = 1000000.0f, e = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float* q = part + ((bh * S + s) * 3) * D + d;
-    a = fmaxf(a, q[0]); c = fminf(c, q[D]); e += q[2 * D];
+  for (int s0 = 0; s0 < S; s0 += 8) {
+    float va[8], vc[8], ve[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = min(s0 + u, S - 1);
+      const float* q = part + ((bh * S + s) * 3) * D + d;
+      va[u] = q[0]; vc[u] = q[D]; ve[u] = q[2 * D];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < S) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); e += ve[u]; }
   }
   float* o = stats + bh * 3 * D + d;
   o[0] = a; o[D] = c; o[2 * D] = e;

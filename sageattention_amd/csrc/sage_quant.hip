@@ -53,7 +53,14 @@ __global__ void k_mean_final_kernel(const float* __restrict__ part, int S, int D
   const int d = threadIdx.x;
   if (d >= D) return;
   float sum = 0.f;
-  for (int s = 0; s < S; ++s) sum += part[(bh * S + s) * D + d];
+  for (int s0 = 0; s0 < S; s0 += 8) {  // 8 partials in flight, added in chunk order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(bh * S + min(s0 + u, S - 1)) * D + d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < S) sum += v[u];
+  }
   km[bh * D + d] = f32_to_elem_bits<BF16>(sum / (float)N);
 }
 

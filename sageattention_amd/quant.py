@@ -7,13 +7,7 @@ from typing import Optional
 
 import torch
 
-import os
-
 from . import _lib as L
-
-# Single-pass pre-pass kernels (csrc/sage_prep.hip): K mean + quantization and the FP8 V quantizer each read their input
-# once in one launch.  SAGEATTN_SINGLE_PASS=0 selects the multi-launch kernels (bit-identical results; kept for A/B).
-SINGLE_PASS = os.environ.get("SAGEATTN_SINGLE_PASS", "1") == "1"
 
 
 def _km3(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torch.Tensor]:
@@ -69,26 +63,6 @@ def k_mean(k: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
     L.check(lib.sage_k_mean(L.desc(k, tensor_layout), L.dtype_code(k.dtype), B, H, N, D, km.data_ptr(), ws.data_ptr(),
                             L.stream_ptr(k.device)), "sage_k_mean")
     return km
-
-
-def k_smooth_quant(k: torch.Tensor, tensor_layout: str, gran: int, rounding: int, dense_heads: bool = True):
-    """``km = k.mean(seq)`` (core.py:612) and the INT8 quantization of ``k - km`` (K half of core.py:621-624) in ONE
-    launch that reads K once (sage_k_prep): bit-identical to ``k_mean`` + ``_quant(..., mean=km)``.
-    Returns (k_int8, k_scale, km [B,H,D])."""
-    B, H, N, D = L.dims(k, tensor_layout)
-    if dense_heads and tensor_layout == "NHD":
-        out = torch.empty((B, H, N, D), dtype=torch.int8, device=k.device).transpose(1, 2)
-    else:
-        out = torch.empty(k.shape, dtype=torch.int8, device=k.device)
-    G = (N + 63) // 64 * (4 if gran == L.GRAN_PER_THREAD else 1)
-    scale = torch.empty((B, H, G), dtype=torch.float32, device=k.device)
-    km = torch.empty((B, H, D), dtype=k.dtype, device=k.device)
-    lib = L.lib()
-    ws = torch.empty(lib.sage_k_prep_workspace_bytes(B, H, N, D) // 4, dtype=torch.float32, device=k.device)
-    L.check(lib.sage_k_prep(L.desc(k, tensor_layout), L.dtype_code(k.dtype), B, H, N, D, L.desc(out, tensor_layout),
-                            scale.data_ptr(), km.data_ptr(), gran, rounding, ws.data_ptr(), L.stream_ptr(k.device)),
-            "sage_k_prep")
-    return out, scale, km
 
 
 def per_block_int8(q, k, km=None, BLKQ=128, BLKK=64, sm_scale=None, tensor_layout="HND", rounding="cuda"):
@@ -151,11 +125,6 @@ def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: floa
     v_scale = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
     vm = torch.empty((B, H, D), dtype=torch.float32, device=v.device) if smooth_v else None
     lib = L.lib()
-    if SINGLE_PASS:  # one launch, V read once (sage_v_prep_fp8); bit-identical to the three-launch form below
-        ws = torch.empty(lib.sage_v_prep_fp8_workspace_bytes(B, H, N, D) // 4, dtype=torch.float32, device=v.device)
-        L.check(lib.sage_v_prep_fp8(L.desc(v, tensor_layout), L.dtype_code(v.dtype), B, H, N, D, od, v_scale.data_ptr(),
-                                    L.ptr(vm), float(scale_max), ws.data_ptr(), L.stream_ptr(v.device)), "sage_v_prep_fp8")
-        return v8, v_scale, vm
     ws = torch.empty(max(1, lib.sage_quant_v_fp8_workspace_bytes(B, H, N, D) // 4), dtype=torch.float32, device=v.device)
     L.check(lib.sage_quant_v_fp8(L.desc(v, tensor_layout), L.dtype_code(v.dtype), B, H, N, D, od, v_scale.data_ptr(),
                                  L.ptr(vm), float(scale_max), ws.data_ptr(), L.stream_ptr(v.device)), "sage_quant_v_fp8")
