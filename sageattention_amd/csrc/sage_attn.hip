@@ -22,6 +22,9 @@
 
 namespace sage {
 
+// K/V slots of the LDS tile ring (see the kernel): 4 for the FP8-PV loop where every wave copies a full share of each tile
+constexpr int attn_ring_slots(int D, int nwaves, bool pv_fp8) { return (pv_fp8 && nwaves * 64 <= 4 * D) ? 4 : 2; }
+
 // PV_FP8 = false: V fp16 [N][D] row major (bf16 converted on the fly), PV on v_mfma_f32_32x32x16_f16.
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
@@ -44,7 +47,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const k_lds = smem;
-  char* const v_lds = smem + 2 * KBYTES;
+  // K/V tile ring in LDS.  FP16 PV: two slots each (K fetched two tiles ahead, V one; every tile copy has ONE iteration to
+  // land and is drained with vmcnt(0) in front of the barrier that publishes it).  FP8 PV: four slots each, K fetched four
+  // tiles ahead and V three, and the per-tile wait leaves the copies of the last two iterations in flight (counted vmcnt):
+  // a copy has three iterations to land, which takes the L2 round trip off the critical path (measured bound of that
+  // latency on the FP8 loop, same-tile ablation: +4.8 %; tiles are half as big, so the ring costs 64 KiB at head_dim 128).
+  // (counted waits need every wave to issue the same number of copies per tile: not so when a tile has fewer 16-B
+  // chunks than the workgroup has threads -- head_dim 64 with 8 waves, a tuning-only geometry, keeps two slots)
+  constexpr int RING = attn_ring_slots(D, NWAVES, PV_FP8);
+  char* const v_lds = smem + RING * KBYTES;
 
   // ---- block -> (b, h, q block), XCD aware: consecutive logical ids (same head) share an L2
   const int nwg = gridDim.x;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     for (int i = 0; i < VC; ++i) {
       if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
       if constexpr (V_DMA)
-        lds_dma16(v_rsrc_dma, (unsigned)(2 * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
+        lds_dma16(v_rsrc_dma, (unsigned)(RING * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
       else
         vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff[i], j * v_tile_stride, 0);
     }
@@ -598,11 +609,29 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   if constexpr (abl::kPrio >= 0) {  // static priority for the second-dispatched half of the workgroup: measured 0 %
     if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(abl::kPrio >= 0 ? abl::kPrio : 0);
   }
-  dma_k(0, 0);
-  load_v(0, 0);
-  store_v(0);
-  if (ntiles > 1) dma_k(1, 1);
-  dma_wait_all();
+  // tile copies a wave issues per iteration (full tiles): the unit of the counted waits of the four-slot ring
+  constexpr int NDMA = KC + VC;
+  static_assert(RING == 2 || (KC * T == 64 * KCH && VC * T == VROWS * VCH), "four-slot ring: every wave copies full shares");
+  const int last_tile = ntiles - 1;
+  if constexpr (RING == 2) {
+    dma_k(0, 0);
+    load_v(0, 0);
+    store_v(0);
+    if (ntiles > 1) dma_k(1, 1);
+    dma_wait_all();
+  } else {
+    // K(0..3) and V(0..2), clamped to the last tile so that every wave issues the same number of copies whatever the
+    // sequence length (a clamped copy re-loads the last tile into a slot nobody reads any more); only K(0), V(0), K(1)
+    // are needed now, the rest keeps flying
+    dma_k(0, 0);
+    load_v(0, 0);
+    dma_k(min(1, last_tile), 1);
+    load_v(min(1, last_tile), 1);
+    dma_k(min(2, last_tile), 2);
+    load_v(min(2, last_tile), 2);
+    dma_k(min(3, last_tile), 3);
+    dma_wait_keep<2 * NDMA>();
+  }
   __syncthreads();
 
   if constexpr (HAS_MASK) {
@@ -648,11 +677,19 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   float4 kk_nxt = load_kscales(min(1, ntiles - 1));
   auto fast_iter = [&](auto par_tag, const int j, v16i (&sa)[2], v16i (&sb)[2], float& a0, float& a1, float& b0,
                        float& b1) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par_tag)::value;  // j & 1, static so every LDS offset is an immediate
+    constexpr int R = decltype(par_tag)::value;  // j % RING, static so every LDS offset is an immediate
+    constexpr int PAR = R & 1;                    // which of the two S register sets is consumed
+    constexpr int K_RD = (R + 1) % RING, V_RD = R, K_WR = R, V_WR = (R + RING - 1) % RING;  // slots of K(j+1), V(j), K(j+RING), V(j+RING-1)
+    (void)PAR;
     maybe_rescale(mx_cur);
     if constexpr (!abl::kNoStage) {
-      if (j + 2 < ntiles) dma_k(j + 2, PAR);
-      load_v(j + 1, PAR ^ 1);
+      if constexpr (RING == 2) {
+        if (j + 2 < ntiles) dma_k(j + 2, K_WR);
+        load_v(j + 1, V_WR);
+      } else {
+        dma_k(min(j + RING, last_tile), K_WR);
+        load_v(min(j + RING - 1, last_tile), V_WR);
+      }
     }
     // scales of tile j+1 were fetched during the previous iteration; fetch those of tile j+2 now (a scalar load
     // issued right in front of its use would expose the scalar-cache latency behind the workgroup barrier)
@@ -660,8 +697,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     kk_nxt = load_kscales(min(j + 2, ntiles - 1));
     constexpr int HAND_PLACED = PV_FP8 ? abl::kHandPlacedF8 : abl::kHandPlacedF16;
     if constexpr (HAND_PLACED == 0) {
-      qk(PAR ^ 1, sb);
-      softmax_pv(j, PAR, sa, a0, a1, std::false_type{});
+      qk(K_RD, sb);
+      softmax_pv(j, V_RD, sa, a0, a1, std::false_type{});
       mx_cur = row_max(sb, b0, b1);
     } else if constexpr (HAND_PLACED == 2) {
       // Hand-placed stream, FP8 PV.  The K = 64 MFMA consumes the P of the whole tile, so all of P(j) precedes the P.V
@@ -671,8 +708,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       // words are computed, and the four P.V MFMAs run beside the row max of S(j+1).
       constexpr int NS = 2 * KS;       // S MFMAs per tile
       constexpr int WPS = 8 / NS;      // P words per S MFMA (1 at head_dim 128, 2 at 64)
-      const char* const kb = k_lds + (PAR ^ 1) * KBYTES;
-      const char* const vb = v_lds + PAR * VBYTES;
+      const char* const kb = k_lds + K_RD * KBYTES;
+      const char* const vb = v_lds + V_RD * VBYTES;
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
         return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
@@ -750,8 +787,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       // the row max of S(j+1) runs beside the last quarter's MFMAs.  sched_barrier(0) pins each group.
       constexpr int NS = 2 * KS, SPR = NS / 4;  // S MFMAs per tile / per region
       constexpr int PPG = 4 / DT;               // P pairs computed beside one P.V MFMA
-      const char* const kb = k_lds + (PAR ^ 1) * KBYTES;
-      const char* const vb = v_lds + PAR * VBYTES;
+      const char* const kb = k_lds + K_RD * KBYTES;
+      const char* const vb = v_lds + V_RD * VBYTES;
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
         if constexpr (abl::kNoLdsK) return qf[i % KS];
@@ -848,13 +885,44 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       mx_cur = swap_max(mx);
     }
     if constexpr (!abl::kNoStage) {
-      store_v(PAR ^ 1);
-      dma_wait_all();
+      if constexpr (RING == 2) {
+        store_v(V_WR);
+        dma_wait_all();
+      } else {
+        dma_wait_keep<2 * NDMA>();  // K(j+2), V(j+1) and everything older have landed; the last two iterations' copies fly on
+      }
     }
     if constexpr (!abl::kNoBar) __syncthreads();
   };
   float nsc0 = 0.f, nsc1 = 0.f;
   int j = 0;
+  if constexpr (RING == 4) {
+    // four-slot ring: the slot pattern repeats every four tiles
+    for (; j + 3 < n_fast; j += 4) {
+      fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+      fast_iter(std::integral_constant<int, 2>{}, j + 2, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      fast_iter(std::integral_constant<int, 3>{}, j + 3, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+    }
+    // up to three fast tiles left (j % 4 == 0 here); after an odd number the live scores sit in the other register set
+    bool odd = false;
+    if (j < n_fast) {
+      fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      ++j; odd = true;
+      if (j < n_fast) {
+        fast_iter(std::integral_constant<int, 1>{}, j, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+        ++j; odd = false;
+        if (j < n_fast) {
+          fast_iter(std::integral_constant<int, 2>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+          ++j; odd = true;
+        }
+      }
+    }
+    if (odd) {
+      s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
+      sc0 = nsc0; sc1 = nsc1;
+    }
+  } else {
   for (; j + 1 < n_fast; j += 2) {
     fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
     fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
@@ -870,17 +938,28 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       ++j;
     }
   }
+  }
+  // generic body (masked / last tiles) and, for causal waves that are done early, staging-only iterations: runtime slots,
+  // every copy drained (vmcnt(0)) -- the four-slot ring keeps its copy COUNT per iteration constant here as well
+  auto stage_generic = [&](const int jj) __attribute__((always_inline)) {
+    if constexpr (RING == 2) {
+      if (jj + 2 < ntiles) dma_k(jj + 2, jj & 1);
+      if (jj + 1 < ntiles) load_v(jj + 1, (jj + 1) & 1);
+    } else {
+      dma_k(min(jj + RING, last_tile), jj % RING);
+      load_v(min(jj + RING - 1, last_tile), (jj + RING - 1) % RING);
+    }
+  };
   for (; j < wave_tiles; ++j) {
     maybe_rescale(mx_cur);
-    if (j + 2 < ntiles) dma_k(j + 2, j & 1);
-    if (j + 1 < ntiles) load_v(j + 1, (j + 1) & 1);
+    stage_generic(j);
     const bool has_next = j + 1 < wave_tiles;
     if (has_next) {
       tile_scales(j + 1, nsc0, nsc1);
-      qk((j + 1) & 1, s_nxt);
+      qk((j + 1) % RING, s_nxt);
       mask_limit(j + 1, s_nxt);
     }
-    softmax_pv(j, j & 1, s_cur, sc0, sc1, std::true_type{});
+    softmax_pv(j, j % RING, s_cur, sc0, sc1, std::true_type{});
     if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
     if (j + 1 < ntiles) store_v((j + 1) & 1);
     dma_wait_all();
@@ -889,8 +968,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     sc0 = nsc0; sc1 = nsc1;
   }
   for (; j < ntiles; ++j) {
-    if (j + 2 < ntiles) dma_k(j + 2, j & 1);
-    if (j + 1 < ntiles) { load_v(j + 1, (j + 1) & 1); store_v((j + 1) & 1); }
+    stage_generic(j);
+    if (j + 1 < ntiles) store_v((j + 1) & 1);
     dma_wait_all();
     __syncthreads();
   }
@@ -964,7 +1043,7 @@ static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf
       return launch_status();
     }
   }
-  const size_t smem = 2 * 64 * D + 2 * (PV_FP8 ? 64 * D : 64 * D * 2);
+  const size_t smem = (size_t)attn_ring_slots(D, NWAVES, PV_FP8) * (64 * D + (PV_FP8 ? 64 * D : 64 * D * 2));  // RING x (K tile + V tile)
   const dim3 grid(p.nqb * p.Hq * p.B), block(NWAVES * 64);
 #define SAGE_LAUNCH(C, K, V)                                                                                       \
   do {                                                                                                             \

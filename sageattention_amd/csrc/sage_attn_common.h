@@ -85,6 +85,14 @@ __device__ __forceinline__ void lds_dma16(v4i rsrc, unsigned lds_off, int voffse
       : "memory");
 #endif
 }
+// counted form: wait until at most N of the wave's vector-memory operations are outstanding (they complete in order)
+template <int N>
+__device__ __forceinline__ void dma_wait_keep() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
 __device__ __forceinline__ void dma_wait_all() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
