@@ -124,7 +124,9 @@ class HipRingBackend:
         g = q.shape[1] // kms.shape[2]
         if g > 1:
             kms = kms.repeat_interleave(g, dim=2)
-        return torch.einsum("bhmd,pbhd->pbhm", q, kms).float().contiguous()
+        # fp32 products and sums (the single-GPU path accumulates q.km in fp32 inside the quantizer; 16-bit outputs would
+        # cost up to ~0.2 in |q.km| with large channel means, i.e. percent-level merge weights)
+        return torch.einsum("bhmd,pbhd->pbhm", q.float(), kms.float()).contiguous()
 
     def block_attn(self, qstate, kv, causal: bool, corr=None):
         """(o_blk [B,H,M,D] in q's dtype, lse [B,H,M] natural log of the true logits) for one KV shard.
@@ -139,7 +141,7 @@ class HipRingBackend:
         if corr is None:
             g = q.shape[1] // kv["km"].shape[1]
             km = kv["km"].repeat_interleave(g, dim=1) if g > 1 else kv["km"]
-            corr = torch.einsum("bhmd,bhd->bhm", q, km).float()
+            corr = torch.einsum("bhmd,bhd->bhm", q.float(), km.float())
         corr = corr.contiguous()
         lse = torch.empty_like(lse2)
         L.check(L.lib().sage_finish_lse(lse2.data_ptr(), corr.data_ptr(), float(sm), lse.data_ptr(), lse2.numel(),
