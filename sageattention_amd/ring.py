@@ -31,8 +31,8 @@ each other:
            once (7 xGMI links in parallel), attends its own shard while the exchange is in flight and then all remote
            shards with ONE more launch of the attention kernel over the gathered records (which form one sequence for
            every head), and merges the two partial results once.  No per-shard LSE corrections (the single correction
-           q.km comes out of the Q quantizer in fp32), no staging copy, no per-shard outputs.  Non-causal and
-           causal/contiguous; the zigzag layout uses "direct".
+           q.km comes out of the Q quantizer in fp32), no staging copy, no per-shard outputs.  Non-causal, causal with
+           contiguous shards, and causal with the zigzag layout (half-shard slots, _gather_zigzag).
   "ring"   P-1 rotation steps, each overlapped with one block of compute; one xGMI link per direction is busy.
   "direct" the 8 GPUs of an MI355X node are fully connected by xGMI (7 links per GPU), so every rank posts its shard to
            ALL peers at once (P-1 isend + P-1 irecv in one RCCL group), computes its local block meanwhile and then
@@ -168,6 +168,14 @@ class HipRingBackend:
         return blocks[0]
 
 
+class KvSlots:
+    """Exchange buffer of the gather schedule: ``buf`` uint8 [slots, bytes], slot p = the quantized K/V records of
+    ``rows`` sequence rows of one rank (tile-major, see HipGatherBackend)."""
+
+    def __init__(self, buf, rows, B, Hk, D):
+        self.buf, self.rows, self.B, self.Hk, self.D = buf, rows, B, Hk, D
+
+
 class HipGatherBackend:
     """Device steps of the "gather" schedule, all through the C ABI (include/sageattn_hip.h, "sequence-parallel
     building blocks").  Tests substitute a CPU backend with the same methods (tests/ring_cpu_backend.py)."""
@@ -194,45 +202,59 @@ class HipGatherBackend:
                                        ws[i * (ws.numel() // c):].data_ptr(), st), "sage_seq_stats")
         return out
 
-    # -- record layout of the exchange buffer
-    def _layout(self, B, Hk, n, D):
+    def reduce(self, all_stats, world, n_total, k, v):
+        """Whole-sequence smoothing mean (and V scale) from the gathered statistics [world][c][B*Hk][3][D]."""
+        B, Hk, _, D = k.shape
+        lib, st, dev = L.lib(), L.stream_ptr(k.device), k.device
+        c, BH = all_stats.shape[1], B * Hk
+        fp8 = self.pv == "fp8"
+        self.km = torch.empty((B, Hk, D), dtype=k.dtype, device=dev)
+        self.v_scale = torch.empty((B, Hk, D), dtype=torch.float32, device=dev) if fp8 else None
+        self.v_coef = torch.empty((B, Hk, 2, D), dtype=torch.float32, device=dev) if fp8 else None
+        self.v_dtype = v.dtype
+        L.check(lib.sage_kv_stats_reduce(all_stats.data_ptr(), all_stats[0, 1].data_ptr() if fp8 else None, world,
+                                         c * BH * 3 * D, BH, D, n_total, L.dtype_code(k.dtype), 448.0, self.km.data_ptr(),
+                                         L.ptr(self.v_scale), L.ptr(self.v_coef), st), "sage_kv_stats_reduce")
+
+    # -- record layout of an exchange slot: per 64-key tile [K int8 of all heads | V | k scales], R bytes
+    def _layout(self, B, Hk, D):
         BH = B * Hk
         kb = BH * 64 * D
         vb = kb * (2 if self.pv == "fp16" else 1)
         sb = (BH * self.pt * 4 + 15) // 16 * 16
-        return BH, kb, vb, kb + vb + sb, n // 64
+        return BH, kb, vb, kb + vb + sb
 
-    def setup(self, all_stats, world, k, v):
-        """Whole-sequence smoothing mean / V scale from the gathered statistics, then K and V of the local shard
-        quantized straight into slot 0 of the exchange buffer.  Returns the buffer, uint8 [world, slot_bytes]."""
+    def new_slots(self, slots, B, Hk, rows, D, device):
+        _, _, _, R = self._layout(B, Hk, D)
+        return KvSlots(torch.empty((slots, rows // 64 * R), dtype=torch.uint8, device=device), rows, B, Hk, D)
+
+    def quantize(self, S, k, v):
+        """K (with the whole-sequence mean) and V of ``S.rows`` local rows straight into slot 0 of S."""
         B, Hk, n, D = k.shape
-        BH, kb, vb, R, T = self._layout(B, Hk, n, D)
-        lib, st, dev = L.lib(), L.stream_ptr(k.device), k.device
-        c = all_stats.shape[1]
-        km = torch.empty((B, Hk, D), dtype=k.dtype, device=dev)
-        fp8 = self.pv == "fp8"
-        v_scale = torch.empty((B, Hk, D), dtype=torch.float32, device=dev) if fp8 else None
-        v_coef = torch.empty((B, Hk, 2, D), dtype=torch.float32, device=dev) if fp8 else None
-        part = c * BH * 3 * D
-        L.check(lib.sage_kv_stats_reduce(all_stats.data_ptr(), all_stats[0, 1].data_ptr() if fp8 else None, world, part, BH, D,
-                                         n * world, L.dtype_code(k.dtype), 448.0, km.data_ptr(), L.ptr(v_scale), L.ptr(v_coef),
-                                         st), "sage_kv_stats_reduce")
-        G = torch.empty((world, T * R), dtype=torch.uint8, device=dev)
-        base = G.data_ptr()
+        assert n == S.rows
+        BH, kb, vb, R = self._layout(B, Hk, D)
+        T = n // 64
+        lib, st = L.lib(), L.stream_ptr(k.device)
+        base = S.buf.data_ptr()
         strides = (ctypes.c_int64 * 3)(Hk * self.pt, self.pt, R // 4)
-        L.check(lib.sage_quant_k_int8_kvtiles(L.desc(k, "HND"), L.dtype_code(k.dtype), B, Hk, n, D, km.data_ptr(),
+        L.check(lib.sage_quant_k_int8_kvtiles(L.desc(k, "HND"), L.dtype_code(k.dtype), B, Hk, n, D, self.km.data_ptr(),
                                               L.SageTensor(base, Hk * 64 * D, 64 * D, D), R, base + kb + vb, strides,
                                               self.kcode, self.rnd, st), "sage_quant_k_int8_kvtiles")
-        if fp8:
+        if self.pv == "fp8":
             L.check(lib.sage_quant_v_fp8_apply(L.desc(v, "HND"), L.dtype_code(v.dtype), B, Hk, n, D,
-                                               L.SageTensor(base + kb, Hk * D * 64, D * 64, 64), R, v_coef.data_ptr(), st),
+                                               L.SageTensor(base + kb, Hk * D * 64, D * 64, 64), R, self.v_coef.data_ptr(), st),
                     "sage_quant_v_fp8_apply")
         else:  # fp16/bf16 V: one strided copy into the tile records (a send buffer must be contiguous anyway)
-            dst = torch.as_strided(G.view(v.dtype), (T, B, Hk, 64, D), (R // 2, Hk * 64 * D, 64 * D, D, 1), kb // 2)
+            dst = torch.as_strided(S.buf.view(v.dtype), (T, B, Hk, 64, D), (R // 2, Hk * 64 * D, 64 * D, D, 1), kb // 2)
             dst.copy_(v.reshape(B, Hk, T, 64, D).permute(2, 0, 1, 3, 4))
-        self.km, self.v_scale, self.v_dtype = km, v_scale, v.dtype
-        self.geom = (B, Hk, n, D)
-        return G
+
+    def setup(self, all_stats, world, k, v):
+        """reduce + new_slots + quantize for whole shards (one slot per rank)."""
+        B, Hk, n, D = k.shape
+        self.reduce(all_stats, world, n * world, k, v)
+        S = self.new_slots(world, B, Hk, n, D, k.device)
+        self.quantize(S, k, v)
+        return S
 
     def prepare_q(self, q, sm_scale, want_corr):
         """Queries quantized once; the smooth-K correction q.km (fp32, core.py:613-617) falls out of the same pass."""
@@ -241,14 +263,22 @@ class HipGatherBackend:
                               dot_vec=self.km if want_corr else None, dot_group=g)
         return {"q": q, "q8": q8, "qs": qs, "sm_scale": sm_scale, "corr": corr}
 
-    def attend(self, qstate, G, pos0, npos, causal):
-        """One launch of the attention kernel over the records of slots [pos0, pos0+npos): (o, raw base-2 LSE)."""
-        B, Hk, n, D = self.geom
-        BH, kb, vb, R, T = self._layout(B, Hk, n, D)
+    def slice_q(self, qstate, r0, r1):
+        """Query rows [r0, r1) (multiples of 128) of a prepared query state."""
+        per = 32 if self.gran == "per_thread" else 4  # q scales per 128 rows (BLKQ 128, WARPQ 32)
+        corr = qstate["corr"]
+        return {"q": qstate["q"][:, :, r0:r1], "q8": qstate["q8"][:, :, r0:r1],
+                "qs": qstate["qs"][:, :, r0 // 128 * per:r1 // 128 * per].contiguous(), "sm_scale": qstate["sm_scale"],
+                "corr": None if corr is None else corr[:, :, r0:r1].contiguous()}
+
+    def attend(self, qstate, S, pos0, npos, causal):
+        """One launch of the attention kernel over the records of slots [pos0, pos0+npos) of S: (o, raw base-2 LSE)."""
+        B, Hk, n, D = S.B, S.Hk, S.rows, S.D
+        BH, kb, vb, R = self._layout(B, Hk, D)
         q, q8, qs = qstate["q"], qstate["q8"], qstate["qs"]
         Hq, M = q.shape[1], q.shape[2]
         lib, st = L.lib(), L.stream_ptr(q.device)
-        base = G.data_ptr() + pos0 * T * R
+        base = S.buf.data_ptr() + pos0 * (n // 64) * R
         o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
         lse2 = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device)
         k8 = L.SageTensor(base, Hk * 64 * D, 64 * D, D)
@@ -291,17 +321,20 @@ class HipGatherBackend:
         return o, lse
 
 
+def _all_gather_stats(st, world, group):
+    if world == 1:
+        return st.unsqueeze(0)
+    flat = torch.empty(world * st.numel(), dtype=st.dtype, device=st.device)
+    dist.all_gather_into_tensor(flat, st.reshape(-1), group=group)
+    return flat.view((world,) + tuple(st.shape))
+
+
 def _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer):
     """schedule="gather" (module docstring).  Slot p of a rank's exchange buffer holds the shard of rank (rank - p) mod P:
     its own shard first, then the ranks before it -- exactly the shards a causal rank needs, contiguously."""
-    st = be.stats(k, v)
-    if world > 1:
-        flat = torch.empty(world * st.numel(), dtype=st.dtype, device=st.device)
-        dist.all_gather_into_tensor(flat, st.reshape(-1), group=group)
-        all_stats = flat.view((world,) + tuple(st.shape))
-    else:
-        all_stats = st.unsqueeze(0)
-    G = be.setup(all_stats, world, k, v)
+    all_stats = _all_gather_stats(be.stats(k, v), world, group)
+    S = be.setup(all_stats, world, k, v)
+    G = S.buf
     qstate = be.prepare_q(q, sm_scale, return_lse)
     nremote = (rank if is_causal else world - 1) if world > 1 else 0           # slots 1 .. nremote are used
     ops = []
@@ -312,12 +345,57 @@ def _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world,
         if p_ <= nremote:
             ops.append(dist.P2POp(dist.irecv, G[p_], peer(src), group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    parts = [be.attend(qstate, G, 0, 1, is_causal)]       # own shard, while the exchange is in flight
+    parts = [be.attend(qstate, S, 0, 1, is_causal)]       # own shard, while the exchange is in flight
     for r in reqs:
         r.wait()
     if nremote:
-        parts.append(be.attend(qstate, G, 1, nremote, False))  # every remote shard in one launch
+        parts.append(be.attend(qstate, S, 1, nremote, False))  # every remote shard in one launch
     return be.merge(parts, qstate, return_lse)
+
+
+def _gather_zigzag(be, q, k, v, sm_scale, return_lse, group, world, rank, peer):
+    """Causal, zigzag layout (rank r owns chunks r and 2P-1-r of 2P, local rows = [lo; hi]) on the gather schedule.
+    Two exchange buffers of half-shard slots:
+        LO  slot p = lo half (chunk s) of rank s = (r - p) mod P          every rank needs every lo half
+        HI  slot p = hi half (chunk 2P-1-s) of rank s = r + p             only ranks before s need its hi half
+    and five launches per rank, the same 2P half-block products on every rank:
+        lo rows (chunk r):        own lo, causal | lo halves of the ranks before r          (LO slots 1..r)
+        hi rows (chunk 2P-1-r):   own hi, causal | ALL lo halves (LO slots 0..P-1) | hi halves of the ranks after r (HI 1..P-1-r)
+    The two causal launches run while the exchange is in flight."""
+    n = q.size(2)
+    h = n // 2
+    B, Hk, _, D = k.shape
+    all_stats = _all_gather_stats(be.stats(k, v), world, group)
+    be.reduce(all_stats, world, n * world, k, v)
+    LO = be.new_slots(world, B, Hk, h, D, k.device)
+    HI = be.new_slots(max(1, world - rank), B, Hk, h, D, k.device)
+    be.quantize(LO, k[:, :, :h], v[:, :, :h])
+    be.quantize(HI, k[:, :, h:], v[:, :, h:])
+    qstate = be.prepare_q(q, sm_scale, return_lse)
+    q_lo, q_hi = be.slice_q(qstate, 0, h), be.slice_q(qstate, h, n)
+    ops = []
+    for p_ in range(1, world):
+        dst, src = (rank + p_) % world, (rank - p_) % world
+        ops.append(dist.P2POp(dist.isend, LO.buf[0], peer(dst), group))      # everybody needs our lo half
+        ops.append(dist.P2POp(dist.irecv, LO.buf[p_], peer(src), group))
+    for s in range(rank + 1, world):                                          # hi halves of the ranks after us
+        ops.append(dist.P2POp(dist.irecv, HI.buf[s - rank], peer(s), group))
+    for d in range(rank):                                                     # ranks before us need our hi half
+        ops.append(dist.P2POp(dist.isend, HI.buf[0], peer(d), group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    lo_parts = [be.attend(q_lo, LO, 0, 1, True)]
+    hi_parts = [be.attend(q_hi, HI, 0, 1, True)]
+    for r in reqs:
+        r.wait()
+    if rank > 0:
+        lo_parts.append(be.attend(q_lo, LO, 1, rank, False))
+    hi_parts.append(be.attend(q_hi, LO, 0, world, False))
+    if rank < world - 1:
+        hi_parts.append(be.attend(q_hi, HI, 1, world - 1 - rank, False))
+    o_lo, l_lo = be.merge(lo_parts, q_lo, return_lse)
+    o_hi, l_hi = be.merge(hi_parts, q_hi, return_lse)
+    o = torch.cat([o_lo, o_hi], dim=2)
+    return o, (torch.cat([l_lo, l_hi], dim=2) if return_lse else None)
 
 
 def _pack(parts):
@@ -382,18 +460,20 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
         return dist.get_global_rank(group, r) if (world > 1 and group is not None) else r
 
     if schedule == "gather":
-        gather_ok = (not zigzag and k.size(2) % 64 == 0 and q.size(0) == k.size(0)
-                     and (backend is None or hasattr(backend, "setup")))
+        gather_ok = (k.size(2) % 64 == 0 and q.size(0) == k.size(0) and (backend is None or hasattr(backend, "setup")))
         if gather_ok and backend is None:  # 32-bit tile offsets span the whole gathered buffer of one launch
             per_tile = k.size(0) * k.size(1) * 64 * D * (3 if pv == "fp16" else 2) + k.size(0) * k.size(1) * 16 + 16
             gather_ok = per_tile * (k.size(2) // 64) * world < (1 << 31) - (1 << 22)
         if gather_ok:
             be = backend if backend is not None else HipGatherBackend(pv, qk_quant_gran)
-            o, lse = _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer)
+            if zigzag:
+                o, lse = _gather_zigzag(be, q, k, v, sm_scale, return_lse, group, world, rank, peer)
+            else:
+                o, lse = _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer)
             if tensor_layout == "NHD":
                 o = o.transpose(1, 2)
             return (o, lse) if return_lse else o
-        schedule = "direct"   # zigzag layout, ragged shards, very large batches: the per-shard path
+        schedule = "direct"   # ragged shards, very large batches: the per-shard path
     be = backend if backend is not None else HipRingBackend(pv, qk_quant_gran)
 
     qstate = be.prepare_q(q, sm_scale)

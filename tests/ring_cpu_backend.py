@@ -66,10 +66,15 @@ class OracleRingBackend:
         return o.to(blocks[0][0].dtype), lse
 
 
+class _Slots:
+    def __init__(self, buf, rows, meta):
+        self.buf, self.rows, self.meta = buf, rows, meta
+
+
 class OracleGatherBackend:
     """CPU stand-in for sageattention_amd.ring.HipGatherBackend (schedule "gather"): whole-sequence smoothing mean and
     V scale from exchanged statistics, shards quantized into one byte slot each, gathered slots attended as ONE sequence.
-    Same method names and call order as the HIP backend; the slot is a plain concatenation of the tensors' bytes."""
+    Same method names and call order as the HIP backend; a slot is a plain concatenation of the tensors' bytes."""
 
     def __init__(self, pv="fp8", qk_quant_gran="per_thread"):
         self.pv, self.gran = pv, qk_quant_gran
@@ -81,40 +86,59 @@ class OracleGatherBackend:
             return torch.stack([xf.amax(2), xf.amin(2), xf.sum(2)], dim=2).reshape(B * H, 3, D)
         return torch.stack([one(k), one(v)] if self.pv == "fp8" else [one(k)])
 
-    def setup(self, all_stats, world, k, v):
-        B, Hk, n, D = k.shape
+    def reduce(self, all_stats, world, n_total, k, v):
+        B, Hk, _, D = k.shape
         ksum = torch.zeros(B * Hk, D)
         for p in range(world):                       # fixed order, as sage_kv_stats_reduce
             ksum = ksum + all_stats[p, 0, :, 2, :]
-        km = (ksum / float(n * world)).to(k.dtype).view(B, Hk, 1, D)
-        if self.gran == "per_thread":
-            gid, ng = O.gid_per_thread_k(n)
-            k8, ks = O.quant_int8_grouped(k, gid, ng, mean=km, rounding="triton", scale_eps=1e-7)
-        else:
-            gid, ng = O.gid_per_block(n, 64)
-            k8, ks = O.quant_int8_grouped(k, gid, ng, mean=km, rounding="cuda")
-        self.km = km.squeeze(2).contiguous()
-        parts = [k8.contiguous(), ks.contiguous()]
+        self.km4 = (ksum / float(n_total)).to(k.dtype).view(B, Hk, 1, D)
+        self.km = self.km4.squeeze(2).contiguous()
         if self.pv == "fp8":
             vmax = all_stats[:, 1, :, 0, :].amax(0).view(B, Hk, D)
             vmin = all_stats[:, 1, :, 1, :].amin(0).view(B, Hk, D)
-            amax = torch.maximum(vmax.abs(), vmin.abs())
-            y = v.float().transpose(2, 3) * (O.FP8_E4M3_MAX / amax).unsqueeze(-1)        # quant.py:318-321 with the GLOBAL amax
+            self.amax = torch.maximum(vmax.abs(), vmin.abs())
+            self.v_scale = self.amax / O.FP8_E4M3_MAX
+
+    def _quantize_parts(self, k, v):
+        n = k.shape[2]
+        if self.gran == "per_thread":
+            gid, ng = O.gid_per_thread_k(n)
+            k8, ks = O.quant_int8_grouped(k, gid, ng, mean=self.km4, rounding="triton", scale_eps=1e-7)
+        else:
+            gid, ng = O.gid_per_block(n, 64)
+            k8, ks = O.quant_int8_grouped(k, gid, ng, mean=self.km4, rounding="cuda")
+        parts = [k8.contiguous(), ks.contiguous()]
+        if self.pv == "fp8":
+            y = v.float().transpose(2, 3) * (O.FP8_E4M3_MAX / self.amax).unsqueeze(-1)   # quant.py:318-321 with the GLOBAL amax
             parts.append(y.clamp(-O.FP8_E4M3_MAX, O.FP8_E4M3_MAX).to(torch.float8_e4m3fn).contiguous())
-            self.v_scale = amax / O.FP8_E4M3_MAX
         else:
             parts.append(v.contiguous())
-        self.meta = [(t.shape, t.dtype) for t in parts]
-        slot = torch.cat([t.view(torch.uint8).reshape(-1) for t in parts])
-        G = torch.zeros((world, slot.numel()), dtype=torch.uint8)
-        G[0] = slot
-        return G
+        return parts
 
-    def _unpack(self, slot):
+    def new_slots(self, slots, B, Hk, rows, D, device):
+        dt = torch.float16
+        probe = self._quantize_parts(torch.zeros(B, Hk, rows, D, dtype=self.km.dtype), torch.zeros(B, Hk, rows, D, dtype=self.km.dtype))
+        meta = [(t.shape, t.dtype) for t in probe]
+        nbytes = sum(t.numel() * t.element_size() for t in probe)
+        return _Slots(torch.zeros((slots, nbytes), dtype=torch.uint8), rows, meta)
+
+    def quantize(self, S, k, v):
+        parts = self._quantize_parts(k, v)
+        assert [(t.shape, t.dtype) for t in parts] == S.meta
+        S.buf[0] = torch.cat([t.view(torch.uint8).reshape(-1) for t in parts])
+
+    def setup(self, all_stats, world, k, v):
+        B, Hk, n, D = k.shape
+        self.reduce(all_stats, world, n * world, k, v)
+        S = self.new_slots(world, B, Hk, n, D, k.device)
+        self.quantize(S, k, v)
+        return S
+
+    def _unpack(self, S, p):
         out, off = [], 0
-        for shape, dt in self.meta:
+        for shape, dt in S.meta:
             nb = int(torch.tensor(shape).prod()) * torch.empty((), dtype=dt).element_size()
-            out.append(slot[off:off + nb].view(dt).view(shape))
+            out.append(S.buf[p][off:off + nb].view(dt).view(shape))
             off += nb
         return out
 
@@ -128,8 +152,15 @@ class OracleGatherBackend:
         corr = O.lse_correction(q, self.km, "HND") if want_corr else None
         return {"q": q, "q8": q8, "qs": qs, "sm_scale": sm_scale, "corr": corr}
 
-    def attend(self, qstate, G, pos0, npos, causal):
-        sl = [self._unpack(G[p]) for p in range(pos0, pos0 + npos)]
+    def slice_q(self, qstate, r0, r1):
+        per = 32 if self.gran == "per_thread" else 4
+        corr = qstate["corr"]
+        return {"q": qstate["q"][:, :, r0:r1], "q8": qstate["q8"][:, :, r0:r1],
+                "qs": qstate["qs"][:, :, r0 // 128 * per:r1 // 128 * per], "sm_scale": qstate["sm_scale"],
+                "corr": None if corr is None else corr[:, :, r0:r1]}
+
+    def attend(self, qstate, S, pos0, npos, causal):
+        sl = [self._unpack(S, p) for p in range(pos0, pos0 + npos)]
         k8 = torch.cat([s[0] for s in sl], dim=2)
         ks = torch.cat([s[1] for s in sl], dim=2)
         v = torch.cat([s[2] for s in sl], dim=3 if self.pv == "fp8" else 2)

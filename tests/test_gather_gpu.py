@@ -20,19 +20,57 @@ def _replay(sa, q, k, v, P, causal, pv, gran, ranks=None, return_lse=True):
     bes = [HipGatherBackend(pv, gran) for _ in range(P)]
     shards = [(k[:, :, r * n:(r + 1) * n], v[:, :, r * n:(r + 1) * n]) for r in range(P)]
     all_stats = torch.stack([bes[r].stats(*shards[r]) for r in range(P)])
-    own = [bes[r].setup(all_stats, P, *shards[r])[0].clone() for r in range(P)]   # every rank's slot 0
+    own = [bes[r].setup(all_stats, P, *shards[r]).buf[0].clone() for r in range(P)]   # every rank's slot 0
     out = {}
     for r in (range(P) if ranks is None else ranks):
-        G = bes[r].setup(all_stats, P, *shards[r])
+        S = bes[r].setup(all_stats, P, *shards[r])
         for p in range(1, P):
-            G[p].copy_(own[(r - p) % P])                                            # the exchange
+            S.buf[p].copy_(own[(r - p) % P])                                        # the exchange
         qs = bes[r].prepare_q(q[:, :, r * n:(r + 1) * n], D ** -0.5, return_lse)
-        parts = [bes[r].attend(qs, G, 0, 1, causal)]
+        parts = [bes[r].attend(qs, S, 0, 1, causal)]
         nrem = r if causal else P - 1
         if nrem:
-            parts.append(bes[r].attend(qs, G, 1, nrem, False))
+            parts.append(bes[r].attend(qs, S, 1, nrem, False))
         out[r] = bes[r].merge(parts, qs, return_lse)
-        del G
+        del S
+    return out
+
+
+def _replay_zigzag(sa, q, k, v, P, pv, gran, ranks=None):
+    """The zigzag / gather steps of every requested rank, serially (sageattention_amd.ring._gather_zigzag with the
+    exchange replaced by copies).  -> {rank: (o [lo; hi], lse)}"""
+    from sageattention_amd.ring import HipGatherBackend, zigzag_split
+    B, Hq, N, D = q.shape
+    n, h = N // P, N // P // 2
+    bes = [HipGatherBackend(pv, gran) for _ in range(P)]
+    loc = [tuple(zigzag_split(t, P, r).contiguous() for t in (q, k, v)) for r in range(P)]
+    all_stats = torch.stack([bes[r].stats(loc[r][1], loc[r][2]) for r in range(P)])
+    lo, hi = [], []
+    for r in range(P):
+        bes[r].reduce(all_stats, P, N, loc[r][1], loc[r][2])
+        a = bes[r].new_slots(1, B, k.shape[1], h, D, k.device); bes[r].quantize(a, loc[r][1][:, :, :h], loc[r][2][:, :, :h])
+        b = bes[r].new_slots(1, B, k.shape[1], h, D, k.device); bes[r].quantize(b, loc[r][1][:, :, h:], loc[r][2][:, :, h:])
+        lo.append(a.buf[0]); hi.append(b.buf[0])
+    out = {}
+    for r in (range(P) if ranks is None else ranks):
+        be = bes[r]
+        LO = be.new_slots(P, B, k.shape[1], h, D, k.device)
+        HI = be.new_slots(max(1, P - r), B, k.shape[1], h, D, k.device)
+        for p in range(P):
+            LO.buf[p].copy_(lo[(r - p) % P])
+        for p in range(P - r):
+            HI.buf[p].copy_(hi[r + p])
+        qs = be.prepare_q(loc[r][0], D ** -0.5, True)
+        q_lo, q_hi = be.slice_q(qs, 0, h), be.slice_q(qs, h, n)
+        lo_parts = [be.attend(q_lo, LO, 0, 1, True)]
+        hi_parts = [be.attend(q_hi, HI, 0, 1, True)]
+        if r > 0:
+            lo_parts.append(be.attend(q_lo, LO, 1, r, False))
+        hi_parts.append(be.attend(q_hi, LO, 0, P, False))
+        if r < P - 1:
+            hi_parts.append(be.attend(q_hi, HI, 1, P - 1 - r, False))
+        (o_lo, l_lo), (o_hi, l_hi) = be.merge(lo_parts, q_lo, True), be.merge(hi_parts, q_hi, True)
+        out[r] = (torch.cat([o_lo, o_hi], dim=2), torch.cat([l_lo, l_hi], dim=2))
     return out
 
 
@@ -80,8 +118,9 @@ def test_tile_major_quantizers_are_bit_identical_to_the_dense_ones():
     v = (torch.randn(B, Hk, n, D, device="cuda") * 3).half()
     be = HipGatherBackend("fp8", "per_thread")
     st = be.stats(k, v)
-    G = be.setup(st.unsqueeze(0), 1, k, v)
-    BH, kb, vb, R, T = be._layout(B, Hk, n, D)
+    G = be.setup(st.unsqueeze(0), 1, k, v).buf
+    BH, kb, vb, R = be._layout(B, Hk, D)
+    T = n // 64
     rec = G[0].view(T, R)
     # statistics and the reduced operands
     assert torch.equal(st[0, :, 2].view(B, Hk, D), k.float().sum(2)) or (st[0, :, 2].view(B, Hk, D) - k.float().sum(2)).abs().max() < 1e-2
@@ -142,3 +181,56 @@ def test_c5_shape_rehearsal_on_one_gpu(causal):
     assert (res[r][0][:, h:h + 1].float().cpu() - ref).abs().max() < 0.1
     assert calc_diff(res[r][0][:, h:h + 1].float().cpu(), ref) < 5e-3
     assert (res[r][1][:, h:h + 1].cpu() - ref_lse).abs().max() < 0.06
+
+
+@pytest.mark.parametrize("pv,gran,D", [("fp8", "per_thread", 128), ("fp16", "per_warp", 64)])
+def test_gather_zigzag_steps_on_one_gpu(pv, gran, D):
+    """Causal / zigzag on the gather schedule (half-shard slots, five launches per rank), replayed serially for 3 ranks:
+    vs exact causal attention and vs the unsharded operator on the whole sequence (same quantized operands)."""
+    import sageattention_amd as sa
+    from oracle import sage_oracle as O
+    from sageattention_amd.ring import zigzag_merge
+    torch.manual_seed(21)
+    B, Hq, Hk, P = 1, 4, 2, 3
+    N = 512 * P
+    q = torch.randn(B, Hq, N, D, dtype=torch.float16, device="cuda")
+    k = (torch.randn(B, Hk, N, D, device="cuda") + 2 * torch.randn(1, Hk, 1, D, device="cuda")).half()
+    v = torch.randn(B, Hk, N, D, dtype=torch.float16, device="cuda")
+    res = _replay_zigzag(sa, q, k, v, P, pv, gran)
+    o = zigzag_merge([res[r][0] for r in range(P)]).float().cpu()
+    lse = zigzag_merge([res[r][1] for r in range(P)]).cpu()
+    ref, ref_lse = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=True, return_lse=True)
+    assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
+    assert (lse - ref_lse).abs().max() < 0.06
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+    o1, l1 = fn(q, k, v, is_causal=True, qk_quant_gran=gran, return_lse=True)
+    assert (o - o1.float().cpu()).abs().max() < (2e-3 if pv == "fp16" else 6e-2)
+    assert (lse - l1.cpu()).abs().max() < 1e-3
+    # world size 1 through the public entry point
+    o2, l2 = sa.ring_sageattn(q, k, v, is_causal=True, pv=pv, qk_quant_gran=gran, return_lse=True, causal_layout="zigzag")
+    assert (o2.float().cpu() - o1.float().cpu()).abs().max() < (2e-3 if pv == "fp16" else 6e-2)
+    assert (l2.cpu() - l1.cpu()).abs().max() < 1e-3
+
+
+def test_c5_shape_zigzag_rehearsal_on_one_gpu():
+    """BASELINE configs[4] at its true per-rank shape, causal with the zigzag layout (4096-row half-shards, 8 ranks):
+    ranks 0, 3, 7 replayed on one GPU against the unsharded causal operator on the whole 64K sequence."""
+    import sageattention_amd as sa
+    from sageattention_amd.ring import zigzag_split
+    torch.manual_seed(19)
+    B, H, P, n, D = 1, 32, 8, 8192, 128
+    N = P * n
+    q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    k = (torch.randn(B, H, N, D, device="cuda") + 2 * torch.randn(1, H, 1, D, device="cuda")).half()
+    v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    ranks = (0, 3, 7)
+    res = _replay_zigzag(sa, q, k, v, P, "fp8", "per_thread", ranks=ranks)
+    o_full, l_full = sa.sageattn_qk_int8_pv_fp8_cuda(q, k, v, is_causal=True, return_lse=True)
+    for r in ranks:
+        o, lse = res[r]
+        of, lf = zigzag_split(o_full, P, r), zigzag_split(l_full, P, r)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        assert (o.float() - of.float()).abs().max() < 6e-2, r     # first rows of chunk 0: a handful of keys, one e4m3 step
+        assert (lse - lf).abs().max() < 1e-3, r
+        assert calc_diff(o.float().cpu(), of.float().cpu()) < 2e-3

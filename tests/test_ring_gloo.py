@@ -147,14 +147,20 @@ def _gather_worker(rank, world, port, cfg, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from ring_cpu_backend import OracleGatherBackend
     from sageattention_amd.ring import ring_sageattn
-    B, Hq, Hk, N, D, causal, pv, layout, gran = cfg
+    B, Hq, Hk, N, D, causal, pv, layout, gran = cfg[:9]
+    zig = len(cfg) > 9 and cfg[9] == "zigzag"
     q, k, v = _inputs(B, Hq, Hk, N, D)
     n = N // world
-    ql, kl, vl = (t[:, :, rank * n:(rank + 1) * n] for t in (q, k, v))
+    if zig:
+        from sageattention_amd.ring import zigzag_split
+        ql, kl, vl = (zigzag_split(t, world, rank) for t in (q, k, v))
+    else:
+        ql, kl, vl = (t[:, :, rank * n:(rank + 1) * n] for t in (q, k, v))
     if layout == "NHD":
         ql, kl, vl = (t.transpose(1, 2).contiguous() for t in (ql, kl, vl))
     o, lse = ring_sageattn(ql, kl, vl, tensor_layout=layout, is_causal=causal, return_lse=True, pv=pv, qk_quant_gran=gran,
-                           backend=OracleGatherBackend(pv=pv, qk_quant_gran=gran), schedule="gather")
+                           backend=OracleGatherBackend(pv=pv, qk_quant_gran=gran), schedule="gather",
+                           causal_layout="zigzag" if zig else "contiguous")
     if layout == "NHD":
         o = o.transpose(1, 2)
     torch.save({"o": o.contiguous(), "lse": lse}, os.path.join(out_dir, f"r{rank}.pt"))
@@ -198,7 +204,7 @@ def test_gather_schedule_matches_the_unsharded_operator(tmp_path, world, causal,
     Gs = [bes[r].setup(all_stats, world, *shards[r]) for r in range(world)]
     for r in range(world):
         for p in range(1, world):
-            Gs[r][p] = Gs[(r - p) % world][0]
+            Gs[r].buf[p] = Gs[(r - p) % world].buf[0]
         qs = bes[r].prepare_q(q[:, :, r * n:(r + 1) * n], D ** -0.5, True)
         parts = [bes[r].attend(qs, Gs[r], 0, 1, causal)]
         nrem = (r if causal else world - 1)
@@ -207,3 +213,27 @@ def test_gather_schedule_matches_the_unsharded_operator(tmp_path, world, causal,
         so, sl = bes[r].merge(parts, qs, True)
         assert torch.equal(so, outs[r]["o"]), f"rank {r} output differs from the serial replay"
         assert torch.equal(sl, outs[r]["lse"])
+
+
+@pytest.mark.parametrize("world,pv,layout,gran", [(2, "fp8", "HND", "per_thread"), (3, "fp16", "NHD", "per_thread"),
+                                                  (4, "fp8", "HND", "per_warp")])
+def test_gather_schedule_zigzag_causal(tmp_path, world, pv, layout, gran):
+    """Causal attention, zigzag layout, on the gather schedule (half-shard slots, five launches per rank): equals exact
+    causal attention and the UNSHARDED oracle operator on the whole sequence (same quantized operands), and every rank
+    does the same number of half-block products."""
+    from oracle import sage_oracle as O
+    from sageattention_amd.ring import zigzag_merge
+    cfg = (1, 4, 2, 256 * world, 64, True, pv, layout, gran, "zigzag")
+    mp.spawn(_gather_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world, join=True)
+    B, Hq, Hk, N, D = cfg[:5]
+    q, k, v = _inputs(B, Hq, Hk, N, D)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=True) for r in range(world)]
+    o = zigzag_merge([x["o"] for x in outs]).float()
+    lse = zigzag_merge([x["lse"] for x in outs])
+    ref, ref_lse = O.sdpa_fp32(q, k, v, is_causal=True, return_lse=True)
+    assert (o - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
+    assert calc_diff(o, ref) < (2e-3 if pv == "fp16" else 5e-3)
+    assert (lse - ref_lse).abs().max() < 0.06
+    oo, ol = O.sageattn_oracle(q, k, v, is_causal=True, qk_quant_gran=gran, pv=pv, return_lse=True)
+    assert (o - oo.float()).abs().max() < (2e-3 if pv == "fp16" else 6e-2)   # fp8: rows with a handful of keys, one e4m3 step
+    assert (lse - ol).abs().max() < 1e-3

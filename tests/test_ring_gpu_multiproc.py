@@ -56,6 +56,8 @@ def _worker(rank, world, port, cfg, out_dir):
     (3, ("ring", 1536, 128, False, "fp8", "gather", "contiguous")),
     (2, ("ring", 1024, 64, True, "fp16", "gather", "contiguous")),
     (2, ("ring", 16384, 128, False, "fp8", "gather", "contiguous", 4, 2)),   # 8192 rows per rank, as C5
+    (2, ("ring", 1024, 128, True, "fp16", "gather", "zigzag")),
+    (3, ("ring", 1536, 64, True, "fp8", "gather", "zigzag")),
 ])
 def test_multi_process_sequence_parallel_on_one_gpu(tmp_path, world, cfg):
     from oracle import sage_oracle as O
@@ -76,7 +78,7 @@ def test_multi_process_sequence_parallel_on_one_gpu(tmp_path, world, cfg):
         import sageattention_amd as sa
         fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
         o1, l1 = fn(q.cuda(), k.cuda(), v.cuda(), is_causal=causal, return_lse=True)
-        assert (o1.cpu().float() - o).abs().max() < (2e-3 if pv == "fp16" else 3e-2)
+        assert (o1.cpu().float() - o).abs().max() < (2e-3 if pv == "fp16" else (6e-2 if causal else 3e-2))
         assert (l1.cpu() - lse).abs().max() < 1e-3
     if mode == "ulysses":  # the exchange only moves data: identical to the single-process operator
         import sageattention_amd as sa
