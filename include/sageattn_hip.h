@@ -250,6 +250,15 @@ int sage_merge_attn_states_multi(const void* const* o_blks, const float* const* 
 int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float* lse_out,
                     int64_t n, sage_stream_t stream);
 
+/* ---- K smoothing + quantization in one call ------------------------------------------
+ * = sage_k_mean + sage_quant_qk_int8(is_key = 1, mean = km, blk 64, mult 1), bit-identical, with the final reduction of
+ * the mean folded into the quantizer for sequences of at most 4096 rows (one launch less where launches are what the
+ * pre-pass costs).  gran: SAGE_GRAN_PER_BLOCK or SAGE_GRAN_PER_THREAD; km: [B,H,D] out (dtype of k); workspace as
+ * sage_k_mean.  Replaces `k.mean` (core.py:612) + quant_per_block_int8_fuse_sub_mean_cuda (fused.cu:594-682) / the K half
+ * of per_thread_int8 (triton/quant_per_thread.py:48-102,162-163). */
+int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H, int N, int D, const sage_tensor* out,
+                        float* scale, void* km, int gran, int rounding, void* workspace, sage_stream_t stream);
+
 /* ==== sequence-parallel building blocks (new: the reference has no parallelism code; its hook is
  * return_lse, core.py:122-124, and its multi-GPU launcher delegates to xDiT, example/parallel_sageattn_cogvideo.py:40-52).
  * With ONE smoothing mean and ONE V scale for the whole sequence (statistics exchanged first: a few KB), the quantized

@@ -65,6 +65,8 @@ SIGNATURES = {
     "sage_merge_attn_states_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sage_finish_lse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sage_set_tuning": (c_int, [c_int, c_int]),
+    "sage_k_smooth_quant": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                    c_void_p]),
     "sage_attn_qk_int8_pv_f16_kvtiles": (c_int, [_P, _P, _P, c_int, _P, c_int, c_void_p, c_void_p, _PL, c_void_p,
                                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                  c_float, c_void_p]),

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib as L
 from . import _qattn
-from .quant import _quant, k_mean, per_channel_fp8, sub_mean
+from .quant import _quant, k_mean, k_smooth_quant, per_channel_fp8, sub_mean
 
 __all__ = ["sageattn", "sageattn_qk_int8_pv_fp16_cuda", "sageattn_qk_int8_pv_fp16_triton",
            "sageattn_qk_int8_pv_fp8_cuda", "sageattn_qk_int8_pv_fp8_cuda_sm90", "sageattn_varlen"]
@@ -105,7 +105,9 @@ def _prep_k(k, tensor_layout, qk_quant_gran, smooth_k):
     inside one launch; one workgroup per head re-reading out of L2) were built and measured SLOWER on MI355X for every
     shape from 2K keys up (pre-pass) -- K's second read is an L2 / Infinity-Cache hit anyway."""
     gran, rnd = _K_QUANT[qk_quant_gran]
-    km = k_mean(k, tensor_layout) if smooth_k else None
+    if smooth_k:
+        return k_smooth_quant(k, tensor_layout, gran, rnd)
+    km = None
     k8, ks, _ = _quant(k, tensor_layout, gran, True, 64, 64, 1.0, rnd, mean=km, dense_heads=True)
     return k8, ks, km
 

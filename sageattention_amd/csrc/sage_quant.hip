@@ -87,6 +87,11 @@ struct QuantParams {
   // result layout: rows of block `blk` start at blk * o_blk (elements; dense: BLK * osn); scales of (b, h, blk) at
   // b*ss_b + h*ss_h + blk*ss_blk (floats; dense: [B,H,G])
   int64_t o_blk, ss_b, ss_h, ss_blk;
+  // mean given as the per-chunk column sums of k_mean_partial_kernel ([B*H][S][D] fp32) instead of `mean`: the kernel
+  // finishes the reduction itself (S <= 16: a few KB per workgroup out of L2) and block 0 stores km -- one launch less
+  const float* mean_part;
+  int S;
+  uint16_t* km_out;
 };
 
 __device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp_shift) {
@@ -121,7 +126,22 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
 
   float mean_f[8];
-  if (p.mean) {
+  if (p.mean_part) {
+    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* pp = p.mean_part + ((int64_t)b * H + h) * p.S * D + tc * 8;
+    for (int s_ = 0; s_ < p.S; ++s_) {  // chunk order, as k_mean_final_kernel
+      const float4 a = *reinterpret_cast<const float4*>(pp + s_ * D), c = *reinterpret_cast<const float4*>(pp + s_ * D + 4);
+      sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w; sum[4] += c.x; sum[5] += c.y; sum[6] += c.z; sum[7] += c.w;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint16_t bits = f32_to_elem_bits<BF16>(sum[j] / (float)p.N);
+      mean_f[j] = elem_to_f32<BF16>(bits);
+      if (j & 1) w[j >> 1] |= (uint32_t)bits << 16; else w[j >> 1] = bits;
+    }
+    if (blk == 0 && tr == 0) *reinterpret_cast<uint4*>(p.km_out + ((int64_t)b * H + h) * D + tc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else if (p.mean) {
     // packed sequences share one mean over all tokens ([1,H,D], core.py:461)
     const uint4 um = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)(p.cu ? 0 : b) * H + h) * D + tc * 8);
     unpack8<BF16>(um, mean_f);
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = xf[i][j];
-      if (p.mean) {
+      if (p.mean || p.mean_part) {
         v = v - mean_f[j];
         if (p.rounding == SAGE_ROUND_TRITON) v = round_to_elem<BF16>(v);  // torch `k - km` in the input dtype
       }
@@ -302,7 +322,8 @@ extern "C" int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N,
 static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int D, const void* mean,
                       const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
                       float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
-                      sage_stream_t stream, const int* cu, int64_t out_blk_stride = 0, const int64_t* scale_strides = nullptr) {
+                      sage_stream_t stream, const int* cu, int64_t out_blk_stride = 0, const int64_t* scale_strides = nullptr,
+                      const float* mean_part = nullptr, int S = 0, void* km_out = nullptr) {
   if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !scale || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
@@ -323,6 +344,7 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   p.out = (int8_t*)out->data; p.osb = out->stride_b; p.osh = out->stride_h; p.osn = out->stride_n;
   p.scale = scale; p.dot_vec = (const uint16_t*)lse_dot_vec; p.dot_out = lse_dot; p.dot_group = dot_group > 0 ? dot_group : 1;
   p.cu = cu;
+  p.mean_part = mean_part; p.S = S; p.km_out = (uint16_t*)km_out;
   p.o_blk = out_blk_stride ? out_blk_stride : (int64_t)blk * out->stride_n;
   p.ss_b = scale_strides ? scale_strides[0] : (int64_t)H * nblk * gpb;
   p.ss_h = scale_strides ? scale_strides[1] : (int64_t)nblk * gpb;
@@ -384,4 +406,36 @@ extern "C" int sage_quant_k_int8_kvtiles(const sage_tensor* k, int dtype, int B,
   if (gran != SAGE_GRAN_PER_BLOCK && gran != SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;  // the K granularities
   return quant_impl(k, dtype, B, H, N, D, mean, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr,
                     out_tile_stride, scale_strides);
+}
+
+// K smoothing + quantization as one call: km = mean over the sequence (sage_k_mean) and the INT8 quantization of k - km
+// (sage_quant_qk_int8 with is_key = 1, blk 64).  Two launches when the sequence has at most 16 chunks of 256 rows (the
+// quantizer finishes the mean itself), three otherwise; bit-identical to the two separate entry points.
+extern "C" int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H, int N, int D, const sage_tensor* out,
+                                   float* scale, void* km, int gran, int rounding, void* workspace, sage_stream_t stream) {
+  if (!km || !workspace) return SAGE_ERR_INVALID_ARGUMENT;
+  if (gran != SAGE_GRAN_PER_BLOCK && gran != SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
+  const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
+  if (S > 16) {
+    const int st = sage_k_mean(k, dtype, B, H, N, D, km, workspace, stream);
+    if (st != SAGE_OK) return st;
+    return quant_impl(k, dtype, B, H, N, D, km, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr);
+  }
+  if (!tensor_ok(k, 8) || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  hipStream_t st = (hipStream_t)stream;
+  launch_begin();
+  const dim3 grid(S, H, B);
+  const uint16_t* kp = (const uint16_t*)k->data;
+  float* ws = (float*)workspace;
+#define LAUNCH(DD, BF)                                                                                         \
+  hipLaunchKernelGGL((k_mean_partial_kernel<DD, BF>), grid, dim3(256), 0, st, kp, k->stride_b, k->stride_h, \
+                     k->stride_n, N, ws, S)
+  if (D == 64) { if (dtype == SAGE_BF16) LAUNCH(64, true); else LAUNCH(64, false); }
+  else { if (dtype == SAGE_BF16) LAUNCH(128, true); else LAUNCH(128, false); }
+#undef LAUNCH
+  if (launch_status() != SAGE_OK) return SAGE_ERR_LAUNCH;
+  return quant_impl(k, dtype, B, H, N, D, nullptr, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr,
+                    0, nullptr, ws, S, km);
 }

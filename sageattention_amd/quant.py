@@ -65,6 +65,26 @@ def k_mean(k: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
     return km
 
 
+def k_smooth_quant(k: torch.Tensor, tensor_layout: str, gran: int, rounding: int, dense_heads: bool = True):
+    """``km = k.mean(seq)`` (core.py:612) and the INT8 quantization of ``k - km`` (K half of core.py:621-624) as one call
+    of the library (sage_k_smooth_quant): bit-identical to ``k_mean`` + ``_quant(..., mean=km)``, one launch less for
+    sequences up to 4096 rows.  Returns (k_int8, k_scale, km [B,H,D])."""
+    B, H, N, D = L.dims(k, tensor_layout)
+    if dense_heads and tensor_layout == "NHD":
+        out = torch.empty((B, H, N, D), dtype=torch.int8, device=k.device).transpose(1, 2)
+    else:
+        out = torch.empty(k.shape, dtype=torch.int8, device=k.device)
+    G = (N + 63) // 64 * (4 if gran == L.GRAN_PER_THREAD else 1)
+    scale = torch.empty((B, H, G), dtype=torch.float32, device=k.device)
+    km = torch.empty((B, H, D), dtype=k.dtype, device=k.device)
+    lib = L.lib()
+    ws = torch.empty(max(1, lib.sage_k_mean_workspace_bytes(B, H, N, D) // 4), dtype=torch.float32, device=k.device)
+    L.check(lib.sage_k_smooth_quant(L.desc(k, tensor_layout), L.dtype_code(k.dtype), B, H, N, D, L.desc(out, tensor_layout),
+                                    scale.data_ptr(), km.data_ptr(), gran, rounding, ws.data_ptr(), L.stream_ptr(k.device)),
+            "sage_k_smooth_quant")
+    return out, scale, km
+
+
 def per_block_int8(q, k, km=None, BLKQ=128, BLKK=64, sm_scale=None, tensor_layout="HND", rounding="cuda"):
     """quant.py:23-104.  ``rounding="triton"`` gives the numerics of triton/quant_per_block.py:48-101."""
     D = q.size(-1)

@@ -702,3 +702,23 @@ def test_c3_headline_config_vs_oracle(sa, gran):
                                        return_lse=True)
             assert (o[sl].cpu().float() - oo.float()).abs().max() < 2e-3
             assert (lse[sl].cpu() - ol).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_k_smooth_quant_is_bit_identical_to_mean_plus_quantizer(sa, layout, dt):
+    """sage_k_smooth_quant (one call; for <= 16 chunks of 256 rows the quantizer finishes the mean itself) against
+    sage_k_mean + sage_quant_qk_int8 (pinned by the reference fixtures above): km, scales and int8 values bit-identical,
+    on ragged and long shapes, both K granularities and roundings."""
+    from sageattention_amd import _lib as L
+    from sageattention_amd.quant import _quant, k_mean, k_smooth_quant
+    for i, (B, H, N, D) in enumerate([(1, 1, 1, 64), (2, 3, 63, 128), (1, 2, 257, 64), (2, 4, 1000, 128), (1, 5, 4096, 64),
+                                      (1, 2, 4097, 128), (2, 8, 8192, 128)]):
+        g = torch.Generator(device="cuda").manual_seed(300 + i)
+        shape = (B, H, N, D) if layout == "HND" else (B, N, H, D)
+        k = (torch.randn(shape, device="cuda", generator=g) * 2 + torch.randn((1, 1, 1, D), device="cuda", generator=g) * 3).to(dt)
+        for gran, rnd in ((L.GRAN_PER_THREAD, L.ROUND_TRITON), (L.GRAN_PER_BLOCK, L.ROUND_CUDA), (L.GRAN_PER_BLOCK, L.ROUND_TRITON)):
+            km = k_mean(k, layout)
+            k8, ks, _ = _quant(k, layout, gran, True, 64, 64, 1.0, rnd, mean=km, dense_heads=True)
+            k8b, ksb, kmb = k_smooth_quant(k, layout, gran, rnd)
+            assert torch.equal(kmb, km) and torch.equal(ksb, ks) and torch.equal(k8b, k8), (B, H, N, D, gran, rnd)
