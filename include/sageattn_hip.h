@@ -72,11 +72,9 @@ const char* sage_status_string(int status);
 /* Compile-time target of the device code in this library ("gfx950"). */
 const char* sage_target_arch(void);
 
-/* Process-wide tuning knobs (speed only, never results).  key SAGE_TUNE_NWAVES: waves per workgroup
- * of the attention kernels, value in {0 = default, 4, 8}.  key SAGE_TUNE_W64: the 64-query-rows-per-wave
- * kernel (one wave per SIMD; head_dim 128, fp16 V), value in {0 = library default, 1 = use where it
- * applies, -1 = never}. */
-typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0, SAGE_TUNE_W64 = 1 } sage_tune_key;
+/* Process-wide tuning knob (speed only, never results).  key SAGE_TUNE_NWAVES: waves per workgroup of the attention
+ * kernels, value in {0 = default, 4, 8}. */
+typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0 } sage_tune_key;
 int sage_set_tuning(int key, int value);
 
 /* ---- K smoothing ---------------------------------------------------------------------------

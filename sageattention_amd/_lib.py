@@ -101,8 +101,6 @@ def lib():
         _lib = l
         if os.environ.get("SAGE_NWAVES"):  # tuning knob (speed only): waves per attention workgroup, 4 or 8
             l.sage_set_tuning(0, int(os.environ["SAGE_NWAVES"]))
-        if os.environ.get("SAGE_W64"):     # 1 = 64-rows-per-wave kernel where it applies, -1 = never
-            l.sage_set_tuning(1, int(os.environ["SAGE_W64"]))
     return _lib
 
 

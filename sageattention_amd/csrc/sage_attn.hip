@@ -1070,7 +1070,6 @@ static bool t_ok(const sage_tensor* t, int align_elems) {
 }
 
 int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
-int g_w64 = 0;              // SAGE_TUNE_W64: 0 = default choice, 1 = force the 64-rows-per-wave kernel where it applies, -1 = never
 
 // shared argument handling of the two attention entry points
 static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
@@ -1146,9 +1145,6 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.q_f16 = fusedq ? (const uint16_t*)q8->data : nullptr;
   p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
-  // 64-rows-per-wave kernel (sage_attn_w64.hip): D = 128, fp16 V, dense, int8 q
-  const bool w64_ok = D == 128 && !pv_fp8 && !vb && !cu_q && !mask && !fusedq && !g_nwaves_override && !kvl;
-  if (w64_ok && g_w64 > 0) return launch_attn_w64(p, D, is_causal, kthread, pv_fp8, st);
   // measured on MI355X: D=128 fp16 PV -> one 8-wave workgroup per CU (4-wave: -3 %); D=128 fp8 PV -> two 4-wave
   // workgroups per CU (+3.6 % non-causal, +5.7 % causal); D=64 (<= 168 VGPRs) -> 4-wave workgroups, 3 per CU
   const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8) ? 4 : 8);
@@ -1167,11 +1163,6 @@ extern "C" int sage_set_tuning(int key, int value) {
   if (key == SAGE_TUNE_NWAVES) {
     if (value != 0 && value != 4 && value != 8) return SAGE_ERR_INVALID_ARGUMENT;
     g_nwaves_override = value;
-    return SAGE_OK;
-  }
-  if (key == SAGE_TUNE_W64) {
-    if (value < -1 || value > 1) return SAGE_ERR_INVALID_ARGUMENT;
-    g_w64 = value;
     return SAGE_OK;
   }
   return SAGE_ERR_INVALID_ARGUMENT;

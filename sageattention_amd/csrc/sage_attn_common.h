@@ -1,4 +1,4 @@
-// Device helpers and the kernel parameter block shared by the attention kernels (sage_attn.hip, sage_attn_w64.hip).
+// Device helpers and the kernel parameter block of the attention kernel (sage_attn.hip).
 #pragma once
 #include <type_traits>
 #include "sage_common.h"
@@ -137,8 +137,5 @@ __device__ __forceinline__ int v_win_swz(int row) {
   // 64-B window XOR for the fp16 V tile so that the 4 rows of a tr-read land on 4 windows
   if constexpr (D == 128) return row & 3; else return (row >> 1) & 1;
 }
-
-// 64-rows-per-wave specialisation (sage_attn_w64.hip); SAGE_ERR_UNSUPPORTED for shapes it does not cover
-int launch_attn_w64(const AttnParams& p, int D, bool causal, bool kthread, bool pv_fp8, hipStream_t st);
 
 }  // namespace sage

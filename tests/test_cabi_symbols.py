@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert l.sage_quant_qk_int8(bad, 0, 1, 1, 8, 96, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -2
     assert l.sage_quant_qk_int8(bad, 7, 1, 1, 8, 64, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -1
     assert l.sage_set_tuning(0, 5) == -1 and l.sage_set_tuning(0, 0) == 0
-    assert l.sage_set_tuning(1, 2) == -1 and l.sage_set_tuning(1, 1) == 0 and l.sage_set_tuning(1, 0) == 0
+    assert l.sage_set_tuning(1, 1) == -1
     assert l.sage_set_tuning(7, 0) == -1
 
 

@@ -257,37 +257,26 @@ def test_full_size_properties(sa):
 
 
 @pytest.mark.parametrize("cfg", [
-    # (B, H, N, D, causal, pv, w64)
-    (4, 32, 2048, 64, True, "fp16", False),   # three waves per SIMD: the configuration in which the round-1 prologue
-    (4, 32, 2048, 64, True, "fp8", False),    # race (K buffer 0 re-filled too early, see sage_attn.hip) showed
-    (4, 32, 2048, 64, False, "fp8", False),
-    (2, 16, 4096, 128, True, "fp16", False),
-    (2, 16, 4096, 128, True, "fp8", False),
-    (2, 16, 2048, 128, True, "fp16", True),   # opt-in 64-rows-per-wave kernel (asm MFMAs)
+    # (B, H, N, D, causal, pv)
+    (4, 32, 2048, 64, True, "fp16"),   # three waves per SIMD: the configuration in which the round-1 prologue
+    (4, 32, 2048, 64, True, "fp8"),    # race (K buffer 0 re-filled too early, see sage_attn.hip) showed
+    (4, 32, 2048, 64, False, "fp8"),
+    (2, 16, 4096, 128, True, "fp16"),
+    (2, 16, 4096, 128, True, "fp8"),
 ])
 def test_run_to_run_determinism(sa, cfg):
     """The operator is a pure function of its inputs: 40 launches on the same tensors, with the whole chip busy (so that
     waves queue on the matrix pipe), must give bit-identical outputs and LSE."""
-    from sageattention_amd import _lib as L
-    B, H, N, D, causal, pv, w64 = cfg
+    B, H, N, D, causal, pv = cfg
     torch.manual_seed(23)
     q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
     k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
     v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
     fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
-    lib = L.lib()
-    keep = sa.core.FUSE_Q_QUANT
-    try:
-        if w64:
-            assert lib.sage_set_tuning(1, 1) == 0
-            sa.core.FUSE_Q_QUANT = False
-        o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
-        for _ in range(40):
-            o, l = fn(q, k, v, is_causal=causal, return_lse=True)
-            assert torch.equal(o, o0) and torch.equal(l, l0)
-    finally:
-        sa.core.FUSE_Q_QUANT = keep
-        lib.sage_set_tuning(1, 0)
+    o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True)
+    for _ in range(40):
+        o, l = fn(q, k, v, is_causal=causal, return_lse=True)
+        assert torch.equal(o, o0) and torch.equal(l, l0)
 
 
 @pytest.mark.parametrize("cfg", [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (2, 32, 4096, 128, True, "fp16"),
@@ -469,46 +458,6 @@ def test_ring_steps_on_one_gpu(sa, pv, causal):
     o1, l1 = ring_sageattn(q, k, v, is_causal=causal, pv=pv, return_lse=True)
     assert (o1.cpu().float() - ref).abs().max() < (0.08 if pv == "fp16" else 0.2)
     assert (l1.cpu() - ref_lse).abs().max() < 0.06
-
-
-@pytest.mark.parametrize("shape", [
-    # (B, Hq, Hk, M, N, causal, gran, layout)
-    (1, 4, 4, 512, 512, False, "per_thread", "HND"),
-    (2, 4, 2, 300, 700, False, "per_warp", "NHD"),     # ragged, GQA, strided heads
-    (1, 2, 2, 1000, 1000, True, "per_thread", "HND"),  # causal, ragged last block
-    (1, 6, 3, 64, 1300, True, "per_warp", "HND"),      # fewer rows than one 256-row workgroup
-])
-def test_w64_kernel_matches_general_kernel(sa, shape):
-    """The opt-in 64-rows-per-wave kernel (sage_attn_w64.hip, SAGE_TUNE_W64) computes the same operator as the default
-    kernel: same quantized operands in, outputs equal to within one fp16 rounding of the lazily rescaled accumulators
-    (the two sub-tiles of a wave rescale together, which may move a row's running max by less than the lazy threshold),
-    LSE equal to 1e-5."""
-    from sageattention_amd import _lib as L
-    B, Hq, Hk, M, N, causal, gran, layout = shape
-    D = 128
-    torch.manual_seed(17)
-    mk = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
-    q = torch.randn(mk(Hq, M), dtype=torch.float16, device="cuda")
-    k = (torch.randn(mk(Hk, N), device="cuda") + 1.5).half()
-    v = torch.randn(mk(Hk, N), dtype=torch.float16, device="cuda")
-    lib = L.lib()
-    try:
-        assert lib.sage_set_tuning(1, -1) == 0
-        o0, l0 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=layout, is_causal=causal, qk_quant_gran=gran,
-                                                  return_lse=True)
-        assert lib.sage_set_tuning(1, 1) == 0
-        sa.core.FUSE_Q_QUANT, keep = False, sa.core.FUSE_Q_QUANT   # the w64 kernel takes int8 q
-        try:
-            o1, l1 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout=layout, is_causal=causal,
-                                                      qk_quant_gran=gran, return_lse=True)
-        finally:
-            sa.core.FUSE_Q_QUANT = keep
-    finally:
-        lib.sage_set_tuning(1, 0)
-    assert torch.isfinite(o1.float()).all()
-    assert (o1.float() - o0.float()).abs().max() <= 2e-3
-    assert calc_diff(o1.float().cpu(), o0.float().cpu()) < 1e-6
-    assert (l1 - l0).abs().max() < 1e-5
 
 
 @pytest.mark.parametrize("pv,gran", [("fp16", "per_thread"), ("fp8", "per_warp")])

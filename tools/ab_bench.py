@@ -47,13 +47,10 @@ for spec in a.libs:
     for name, (res, args) in L.SIGNATURES.items():
         if hasattr(l, name):
             fn = getattr(l, name); fn.restype, fn.argtypes = res, args
-    variants.append((spec, l, nw if nw == "w64" else (int(nw) if nw else 0)))
+    variants.append((spec, l, int(nw) if nw else 0))
 st = torch.cuda.current_stream().cuda_stream
 def run(l, nw):
-    if nw == "w64":
-        l.sage_set_tuning(0, 0); l.sage_set_tuning(1, 1)
-    else:
-        l.sage_set_tuning(0, nw); l.sage_set_tuning(1, -1)
+    l.sage_set_tuning(0, nw)
     if a.pv == "fp8":
         r = l.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, L.desc(o, "HND"), 0, qs.data_ptr(),
                                       ks.data_ptr(), vs.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
