@@ -77,6 +77,12 @@ constexpr int kPrio = SAGE_EXP_PRIO;
 constexpr int kPrio = -1;
 #endif
 
+#ifdef SAGE_EXP_LIGHT_FIRST  // causal: lightest q-blocks of a head first (measured: -1..2 %, MORE L2 misses; see the kernel)
+SAGE_ABL_FLAG(kLightFirst, true);
+#else
+SAGE_ABL_FLAG(kLightFirst, false);
+#endif
+
 // Mechanism probes of the round-2 race fix (profiles/r02_race_evidence.md, tools/race_probe.sh)
 #ifdef SAGE_EXP_DELAY_WAVE           // wave 1 sleeps ~8 us between the prologue barrier and its K(0) fragment reads
 SAGE_ABL_FLAG(kDelayWave, true);
