@@ -113,7 +113,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on the process's stdout (fd 1) at communicator creation; the contract is ONE JSON
+        # line on stdout, so everything the libraries write goes to stderr until the result line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -253,6 +259,10 @@ def main():
             port, sdpa = cpu_baseline(D, causal)
             out["cpu_baseline"] = port
             out["cpu_sdpa"] = sdpa
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
