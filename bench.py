@@ -259,14 +259,14 @@ def main():
             port, sdpa = cpu_baseline(D, causal)
             out["cpu_baseline"] = port
             out["cpu_sdpa"] = sdpa
+    if use_dist:
+        dist.destroy_process_group()
     if saved_stdout is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
