@@ -52,6 +52,34 @@ def test_argument_validation_without_gpu(built_lib):
     assert l.sage_set_tuning(7, 0) == -1
 
 
+def test_sequence_parallel_entry_points_validate_arguments(built_lib):
+    """The round-2 building blocks (kv tile layouts, statistics, tile-major quantizers, merge_ex) reject bad arguments on
+    the host, before any launch."""
+    import ctypes as C
+    from sageattention_amd import _lib as L
+    l = L.lib()
+    t = L.SageTensor(16, 64, 64, 64)
+    lay = L.KvLayout(0, 0, 0, 0, 0)
+    args = (1, 1, 1, 64, 64, 64, 0, 3, 128, 32, 0.125, None)
+    assert l.sage_attn_qk_int8_pv_f16_kvtiles(t, t, t, 0, t, 0, 16, 16, None, None, *args) == -1          # no layout
+    assert l.sage_attn_qk_int8_pv_f8_kvtiles(t, t, t, t, 0, 16, 16, 16, None, None, *args) == -1
+    bad = L.KvLayout(-64, 0, 0, 0, 0)
+    assert l.sage_attn_qk_int8_pv_f16_kvtiles(t, t, t, 0, t, 0, 16, 16, bad, None, *args) == -1           # negative stride
+    odd = L.KvLayout(0, 0, 6, 2, 2)
+    assert l.sage_attn_qk_int8_pv_f16_kvtiles(t, t, t, 0, t, 0, 16, 16, odd, None, *args) == -1           # scale strides < 4
+    assert l.sage_seq_stats(t, 0, 1, 1, 64, 96, 16, 16, None) == -2                                       # head_dim
+    assert l.sage_seq_stats(t, 0, 1, 1, 64, 64, None, 16, None) == -1
+    assert l.sage_kv_stats_reduce(None, None, 1, 192, 1, 64, 64, 0, 448.0, None, None, None, None) == -1
+    assert l.sage_kv_stats_reduce(16, None, 2, 10, 1, 64, 64, 0, 448.0, 16, None, None, None) == -1       # part stride too small
+    st3 = (C.c_int64 * 3)(4, 4, 4)
+    assert l.sage_quant_k_int8_kvtiles(t, 0, 1, 1, 64, 64, None, t, 0, 16, st3, 3, 0, None) == -1         # no tile stride
+    assert l.sage_quant_k_int8_kvtiles(t, 0, 1, 1, 64, 64, None, t, 4096, 16, st3, 2, 0, None) == -1      # per_warp is a Q granularity
+    assert l.sage_quant_v_fp8_apply(t, 0, 1, 1, 64, 64, t, 24, 16, None) == -1                            # unaligned tile stride
+    assert l.sage_k_smooth_quant(t, 0, 1, 1, 64, 64, t, 16, None, 3, 0, 16, None) == -1                   # km missing
+    op = (C.c_void_p * 1)(16)
+    assert l.sage_merge_attn_states_multi_ex(op, op, 1, 0, 16, None, 4, 64, 0.0, None, 0.0, None) == -1   # lse multiplier must be > 0
+
+
 def test_product_path_has_no_oracle_import():
     """The shipped package must never import the oracle or fall back to CPU."""
     pkg = os.path.join(ROOT, "sageattention_amd")
