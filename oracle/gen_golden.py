@@ -40,6 +40,9 @@ CASES = [
     ("gqa_causal_320", 1, 8, 2, 320, 320, 64, "HND", "fp16", True, 1.0),
     ("cross_100x200", 1, 2, 2, 100, 200, 64, "HND", "fp16", False, 0.0),  # M != N, ragged both
     ("bf16_d128", 1, 2, 2, 256, 256, 128, "NHD", "bf16", False, 3.0),
+    # round 2: head_dim 128 causal with several K tiles per q-block, and a bf16 / GQA / NHD / causal combination
+    ("d128_causal_384", 1, 4, 2, 384, 384, 128, "HND", "fp16", True, 2.0),
+    ("bf16_gqa_causal_nhd", 1, 4, 2, 256, 256, 64, "NHD", "bf16", True, 1.0),
 ]
 
 
@@ -109,9 +112,13 @@ def gen_masked():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    gen_varlen()
-    gen_masked()
+    only = set(sys.argv[1:])   # optional: names of the cases to (re)generate; seeds depend on the case's index only
+    if not only:
+        gen_varlen()
+        gen_masked()
     for i, (name, B, Hq, Hk, M, N, D, layout, dt, causal, kbias) in enumerate(CASES):
+        if only and name not in only:
+            continue
         torch.manual_seed(1000 + i)
         dtype = torch.float16 if dt == "fp16" else torch.bfloat16
         shp = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
