@@ -23,3 +23,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c4_pmc_fetch -- python3 $
 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $OUT/c4_pmc_write -- python3 $R/tools/run_attn.py c4 3 > $OUT/c4_pmc_write.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/c4_pmc_clk -- python3 $R/tools/run_attn.py c4 3 > $OUT/c4_pmc_clk.log 2>&1 || true
 python3 $R/tools/pmc_summary.py attn_i8_kernel $OUT/${TAG}_attn_c4_pmc.json $OUT/c4_pmc1 $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_clk
+# and for C2 (head_dim 64, 2K keys, FP16 PV): the configuration furthest below the MFMA roofline
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/c2_pmc1 -- python3 $R/tools/run_attn.py c2 5 > $OUT/c2_pmc1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c2_pmc_fetch -- python3 $R/tools/run_attn.py c2 5 > $OUT/c2_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $OUT/c2_pmc_write -- python3 $R/tools/run_attn.py c2 5 > $OUT/c2_pmc_write.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/c2_pmc_clk -- python3 $R/tools/run_attn.py c2 5 > $OUT/c2_pmc_clk.log 2>&1 || true
+python3 $R/tools/pmc_summary.py attn_i8_kernel $OUT/${TAG}_attn_c2_pmc.json $OUT/c2_pmc1 $OUT/c2_pmc_fetch $OUT/c2_pmc_write $OUT/c2_pmc_clk
