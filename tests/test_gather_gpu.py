@@ -234,3 +234,26 @@ def test_c5_shape_zigzag_rehearsal_on_one_gpu():
         assert (o.float() - of.float()).abs().max() < 6e-2, r     # first rows of chunk 0: a handful of keys, one e4m3 step
         assert (lse - lf).abs().max() < 1e-3, r
         assert calc_diff(o.float().cpu(), of.float().cpu()) < 2e-3
+
+
+def test_gather_bf16_inputs_fp16_pv():
+    """bf16 q/k/v through the gather schedule with the FP16-PV operator: the V records stay bf16 in the exchange slots and
+    are converted on the fly by the kernel's register-staged path (tile-major strides there as well)."""
+    import sageattention_amd as sa
+    from oracle import sage_oracle as O
+    torch.manual_seed(29)
+    B, Hq, Hk, P, n, D = 1, 4, 2, 3, 256, 128
+    N = P * n
+    q = torch.randn(B, Hq, N, D, device="cuda").bfloat16()
+    k = (torch.randn(B, Hk, N, D, device="cuda") + 2 * torch.randn(1, Hk, 1, D, device="cuda")).bfloat16()
+    v = torch.randn(B, Hk, N, D, device="cuda").bfloat16()
+    for causal in (False, True):
+        res = _replay(sa, q, k, v, P, causal, "fp16", "per_thread")
+        o = torch.cat([res[r][0] for r in range(P)], dim=2)
+        lse = torch.cat([res[r][1] for r in range(P)], dim=2)
+        assert o.dtype == torch.bfloat16
+        o1, l1 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=causal, return_lse=True)
+        assert (o.float() - o1.float()).abs().max() < 1.6e-2      # bf16 outputs: 2 ulp at |o| ~ 1
+        assert (lse - l1).abs().max() < 1e-3
+        ref = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=causal)
+        assert (o.float().cpu() - ref).abs().max() < 0.08
