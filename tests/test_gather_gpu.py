@@ -257,3 +257,41 @@ def test_gather_bf16_inputs_fp16_pv():
         assert (lse - l1).abs().max() < 1e-3
         ref = O.sdpa_fp32(q.cpu(), k.cpu(), v.cpu(), is_causal=causal)
         assert (o.float().cpu() - ref).abs().max() < 0.08
+
+
+def test_c5_shape_per_shard_schedules_on_one_gpu():
+    """The round-1 per-shard schedules ("direct" / "ring": per-shard smoothing, per-shard outputs, multi-way merge) at the
+    true C5 per-rank shape, last rank (8 blocks of 8192 x 8192, FP8 PV), non-causal and causal-zigzag half-blocks, against
+    the unsharded operator (different smoothing statistics per shard: operator-level tolerance) and one head of exact
+    attention."""
+    import sageattention_amd as sa
+    from oracle import sage_oracle as O
+    from sageattention_amd.ring import HipRingBackend
+    torch.manual_seed(23)
+    B, H, P, n, D = 1, 32, 8, 8192, 128
+    N = P * n
+    q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    k = (torch.randn(B, H, N, D, device="cuda") + 2 * torch.randn(1, H, 1, D, device="cuda")).half()
+    v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+    be = HipRingBackend("fp8", "per_thread")
+    r = P - 1
+    qs = be.prepare_q(q[:, :, r * n:(r + 1) * n].contiguous(), D ** -0.5)
+    shards = [be.prepare_kv(k[:, :, s * n:(s + 1) * n].contiguous(), v[:, :, s * n:(s + 1) * n].contiguous()) for s in range(P)]
+    corrs = be.lse_corrections(qs, shards)
+    for causal in (False, True):
+        blks = [be.block_attn(qs, shards[s], causal and s == r, corr=corrs[s]) for s in range(P)]
+        o, lse = be.merge_all(blks)
+        o_full, l_full = sa.sageattn_qk_int8_pv_fp8_cuda(q, k, v, is_causal=causal, return_lse=True)
+        rows = slice(r * n, (r + 1) * n)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        assert (o.float() - o_full[:, :, rows].float()).abs().max() < 0.1
+        assert (lse - l_full[:, :, rows]).abs().max() < 0.05
+        h = 7
+        qh, kh, vh = q[:, h:h + 1, rows].cpu(), k[:, h:h + 1].cpu(), v[:, h:h + 1].cpu()
+        s_ = (qh.float() @ kh.float().transpose(2, 3)) * D ** -0.5
+        if causal:
+            s_ = s_.masked_fill(~(torch.arange(r * n, (r + 1) * n).view(-1, 1) >= torch.arange(N).view(1, -1)), float("-inf"))
+        ref, ref_lse = torch.softmax(s_, -1) @ vh.float(), torch.logsumexp(s_, -1)
+        assert (o[:, h:h + 1].float().cpu() - ref).abs().max() < 0.1
+        assert calc_diff(o[:, h:h + 1].float().cpu(), ref) < 5e-3
+        assert (lse[:, h:h + 1].cpu() - ref_lse).abs().max() < 0.06
