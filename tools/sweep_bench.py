@@ -9,7 +9,8 @@ Two measurements per operator, as two markdown tables on stdout:
                (bench/bench_qk_int8_pv_fp16_cuda.py:36-59; "excluding the quantization and smoothing", bench/README.md:63).
                The operands are the real quantizer outputs of the same random fp16 tensors, not randint.
   end-to-end   the public entry point: K mean, quantizers (Q folded into the kernel up to 4096 rows), attention.
-TFLOPS = 4*B*H*N^2*D/t (/2 causal), bench/bench_baseline.py:31.  Speedups are against FA2-ROCm on the same fp16 tensors."""
+TFLOPS = 4*B*H*N^2*D/t (/2 causal), bench/bench_baseline.py:31.  Speedups are against FA2-ROCm on the same fp16 tensors.
+``--flush``: every timed call starts from cold caches (see timeit)."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +19,23 @@ from sageattention_amd import _lib as L, _qattn, core
 from torch.nn.attention import SDPBackend, sdpa_kernel
 
 
+FLUSH = "--flush" in sys.argv   # cold caches: overwrite a 512 MiB buffer (L2 + 256 MiB Infinity Cache) before EVERY timed call,
+_flush_buf = None               # as the reference's bench helper does (bench/utils.py:9-12); one event pair per call
+
+
 def timeit(f, n):
+    global _flush_buf
+    if FLUSH:
+        if _flush_buf is None:
+            _flush_buf = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+        for _ in range(2): f()
+        ts = []
+        for _ in range(max(5, min(n, 15))):
+            _flush_buf.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts)
     for _ in range(3): f()
     ts = []
     for _ in range(3):
