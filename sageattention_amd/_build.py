@@ -19,7 +19,8 @@ SOURCES = [
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
 ]
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+# -Wno-inline-asm: lds_dma16 names M0 in its clobber list, which clang reports as "reserved register" (see the function)
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
           "-Rpass-analysis=kernel-resource-usage"]
 
 
@@ -36,6 +37,33 @@ def _check_no_scratch(src, compiler_output):
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and int(m.group(1)) != 0:
             raise RuntimeError(f"{src}: kernel {name} uses {m.group(1)} bytes/lane of scratch (register spill)")
+
+
+def _check_m0_private(obj):
+    """lds_dma16 (sage_attn_common.h) sets M0 and declares it clobbered instead of saving and restoring it; clang does not
+    honour clobbers of reserved registers, so this is only sound while nothing else in the device code touches M0.
+    Checked on the object that is about to be linked: every M0 reference must be one of those scalar moves."""
+    import glob
+    import re
+    import shutil
+    import tempfile
+    objdump = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-objdump")
+    if not os.path.exists(objdump):
+        objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    tmp = tempfile.mkdtemp(prefix="sage_m0_")
+    try:
+        local = os.path.join(tmp, "o.o")
+        shutil.copy(obj, local)
+        subprocess.run([objdump, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        dev = glob.glob(local + ".*" + ARCH)
+        if not dev:
+            raise RuntimeError(f"{obj}: no {ARCH} code object found")
+        dis = subprocess.run([objdump, "-d", dev[0]], stdout=subprocess.PIPE, text=True, check=True).stdout
+        bad = [l.strip() for l in dis.splitlines() if re.search(r"\bm0\b", l) and not re.search(r"s_mov_b32 m0, s\d+", l)]
+        if bad:
+            raise RuntimeError(f"{obj}: M0 is used outside lds_dma16:\n" + "\n".join(bad[:5]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _stale(target, deps):
@@ -86,6 +114,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         try:
             _check_no_scratch(src, out)
+            if src == "sage_attn.hip":
+                _check_m0_private(os.path.join(CSRC, "sage_attn.o"))
         except RuntimeError:
             os.remove(os.path.join(CSRC, src.replace(".hip", ".o")))  # never link (or cache) a spilling object
             raise

@@ -224,13 +224,19 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   const unsigned v_bytes = PV_FP8 ? (unsigned)((int64_t)last_t * v_tile_stride + (int64_t)(D - 1) * p.vsn + 64)
                                   : (unsigned)((int64_t)last_t * v_tile_stride + ((int64_t)last_r * p.vsn + D) * 2);
   const v4i k_rsrc = make_rsrc(kg, k_bytes), v_rsrc_dma = make_rsrc(vg, v_bytes);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
   // LDS-DMA (buffer_load ... lds): a wave instruction writes 64 x 16 B = 1 KiB of LDS LINEARLY (wave-uniform
   // base + 16*lane), so the bank swizzle of the tile image is applied to the per-lane SOURCE offset instead:
   // LDS chunk position c of a tile holds global chunk (row(c), pos(c) ^ swizzle(row)).  No VGPR staging, no
   // ds_write, and the copy has a whole iteration to land (it is drained by the vmcnt(0) of the next barrier).
-  // bf16 V needs the fp16 conversion (core.py:633) and keeps the register path.
-  constexpr bool V_DMA = !V_BF16;
+  // bf16 V needs the fp16 conversion of core.py:633.
+  //   head_dim 64 : the tile is copied raw like an fp16 one, and once the wave's own copies have landed (vmcnt(0)) it
+  //                 converts exactly the 1 KiB slices it copied, IN PLACE, in front of the barrier that publishes the tile:
+  //                 no registers held across the iteration, so the bf16 variants keep the 168 registers / three waves per
+  //                 SIMD of the fp16 ones (register path: 178-181, two waves; C2 in bf16 +7.5 %, causal +12 %).
+  //   head_dim 128: register path (global -> VGPRs at the top of the iteration, convert + ds_write at its end).  Occupancy
+  //                 is two waves either way, and the extra LDS round trip of the in-place form costs 2-7 % there.
+  constexpr bool V_REG = V_BF16 && D == 128;
+  constexpr bool V_INPLACE = V_BF16 && D == 64;
   int k_voff[KC], v_voff[VC];
 #pragma unroll
   for (int i = 0; i < KC; ++i) {
@@ -243,14 +249,16 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     if constexpr (PV_FP8) {
       v_voff[i] = vr * (int)p.vsn + ((pos ^ ((vr >> 2) & 3)) << 4);  // V^T row vr (= channel), 16-B chunk swizzle
     } else {
-      const int cc = V_DMA ? ((((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3)) : pos;
+      const int cc = V_REG ? pos : ((((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3));
       v_voff[i] = (vr * (int)p.vsn + cc * 8) * 2;
     }
   }
   typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
-  u32x4 vreg[V_DMA ? 1 : VC];
-  int v_wr[V_DMA ? 1 : VC];
-  if constexpr (!V_DMA) {
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
+  (void)v_rsrc;
+  u32x4 vreg[V_REG ? VC : 1];
+  int v_wr[V_REG ? VC : 1];
+  if constexpr (V_REG) {
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
       const int c = tid + i * T, vr = c / VCH, cc = c % VCH;
@@ -265,29 +273,52 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       if (KC * T == 64 * KCH || wave * 64 + i * T < 64 * KCH)
         lds_dma16(k_rsrc, (unsigned)(buf * KBYTES + (wave * 64 + i * T) * 16), k_voff[i], j * k_tile_stride);
   };
-  // V(j) -> V buffer `buf` (DMA), or -> registers (bf16 path; written to LDS by store_v)
+  // V(j) -> V buffer `buf` (DMA), or -> registers (V_REG; written to LDS by finish_tile)
   auto load_v = [&](int j, const int buf) __attribute__((always_inline)) {
     if constexpr (abl::kSameTile) j = 0;
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
       if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
-      if constexpr (V_DMA)
-        lds_dma16(v_rsrc_dma, (unsigned)(RING * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
-      else
+      if constexpr (V_REG)
         vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff[i], j * v_tile_stride, 0);
+      else
+        lds_dma16(v_rsrc_dma, (unsigned)(RING * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
     }
   };
-  auto store_v = [&](const int buf) __attribute__((always_inline)) {
-    if constexpr (!V_DMA) {
+  auto bf16x8_to_f16x8 = [&](u32x4 u) __attribute__((always_inline)) -> u32x4 {
+    float f[8];
+    unpack8<true>(make_uint4(u[0], u[1], u[2], u[3]), f);
 #pragma unroll
-      for (int i = 0; i < VC; ++i) {
-        u32x4 u = vreg[i];
-        float f[8];
-        unpack8<true>(make_uint4(u[0], u[1], u[2], u[3]), f);
+    for (int e = 0; e < 4; ++e)
+      u[e] = (uint32_t)f32_to_elem_bits<false>(f[2 * e]) | ((uint32_t)f32_to_elem_bits<false>(f[2 * e + 1]) << 16);
+    return u;
+  };
+  // End of a two-slot iteration, in front of the barrier that publishes K/V buffer contents: every copy of this wave has
+  // landed, and (bf16 V, if `has_v`) the tile in V buffer `buf` is fp16.
+  auto finish_tile = [&](const int buf, const bool has_v) __attribute__((always_inline)) {
+    if constexpr (V_REG) {
+      if (has_v) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          u[e] = (uint32_t)f32_to_elem_bits<false>(f[2 * e]) | ((uint32_t)f32_to_elem_bits<false>(f[2 * e + 1]) << 16);
-        *reinterpret_cast<u32x4*>(v_lds + buf * VBYTES + v_wr[i]) = u;
+        for (int i = 0; i < VC; ++i) *reinterpret_cast<u32x4*>(v_lds + buf * VBYTES + v_wr[i]) = bf16x8_to_f16x8(vreg[i]);
+      }
+      dma_wait_all();
+    } else {
+      dma_wait_all();
+      if constexpr (V_INPLACE) {
+        if (has_v) {
+          // the lane id is re-derived here (2 VALU) instead of keeping an address register alive through the loop: these
+          // variants sit exactly at the 168 registers that allow three waves per SIMD
+          int ln;
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+          char* const own = v_lds + buf * VBYTES + (wave * 64 + ln) * 16;
+#pragma unroll
+          for (int i = 0; i < VC; ++i) {
+            if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
+            u32x4* const ptr = reinterpret_cast<u32x4*>(own + i * T * 16);
+            *ptr = bf16x8_to_f16x8(*ptr);
+            if (i + 1 < VC) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
   };
@@ -525,7 +556,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     }
   };
   // p = exp2(t - m) and O^T += V^T . P^T
-  uint32_t bits_cur = 0xffffffffu, bits_nxt = 0xffffffffu;  // allow masks of tiles j / j+1 (generic loop only)
+  uint32_t bits_cur = 0xffffffffu;  // allow mask of tile j (attn_mask loop only)
   auto softmax_pv = [&](const int j, const int vbuf, const v16i (&s)[2], const float sc0, const float sc1,
                         auto masked_tag) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_tag)::value;
@@ -600,7 +631,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
 
   // ---- software pipeline.  LDS: K(j) in K buffer j&1, V(j) in V buffer j&1.  During iteration j the wave
   //      computes S(j+1) = K(j+1).Q^T (MFMA) while it exponentiates S(j) (VALU) and accumulates P(j).V(j);
-  //      K(j+2) and V(j+1) travel global -> registers during the iteration and registers -> LDS at its end.
+  //      K(j+2) and V(j+1) are copied global -> LDS during the iteration (LDS-DMA, drained in front of the barrier).
   //   [0, n_fast)           tiles j and j+1 both unmasked: branch-free body
   //   [n_fast, wave_tiles)  generic body (masks, last tile)
   //   [wave_tiles, ntiles)  causal only: this wave is done but still stages tiles for its workgroup
@@ -620,9 +651,8 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   if constexpr (RING == 2) {
     dma_k(0, 0);
     load_v(0, 0);
-    store_v(0);
     if (ntiles > 1) dma_k(1, 1);
-    dma_wait_all();
+    finish_tile(0, true);
   } else {
     // K(0..3) and V(0..2), clamped to the last tile so that every wave issues the same number of copies whatever the
     // sequence length (a clamped copy re-loads the last tile into a slot nobody reads any more); only K(0), V(0), K(1)
@@ -687,8 +717,14 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     (void)PAR;
     // The first K fragment of S(j+1) is read BEFORE the tile copies are issued: the first S MFMA needs it at once, and the
     // copies are inline asm with a memory clobber, so the compiler cannot hoist the read across them itself (+0.2..0.8 %).
+    // scales of tile j+1 were fetched during the previous iteration; those of tile j+2 are fetched first thing here: the
+    // scalar load shares lgkmcnt with the LDS reads, so it must be in flight long before the first wait on a K fragment
+    // (left to hipcc it is issued right in front of that wait and every iteration pays a scalar-cache round trip)
+    scales_from(kk_nxt, b0, b1);
+    kk_nxt = load_kscales(min(j + 2, ntiles - 1));
     v4i kf_early = qf[0];
     if constexpr (!abl::kNoLdsK) kf_early = *reinterpret_cast<const v4i*>(k_lds + K_RD * KBYTES + k_rd[0]);
+    __builtin_amdgcn_sched_barrier(0);
     maybe_rescale(mx_cur);
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
@@ -699,10 +735,6 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         load_v(min(j + RING - 1, last_tile), V_WR);
       }
     }
-    // scales of tile j+1 were fetched during the previous iteration; fetch those of tile j+2 now (a scalar load
-    // issued right in front of its use would expose the scalar-cache latency behind the workgroup barrier)
-    scales_from(kk_nxt, b0, b1);
-    kk_nxt = load_kscales(min(j + 2, ntiles - 1));
     constexpr int HAND_PLACED = PV_FP8 ? abl::kHandPlacedF8 : abl::kHandPlacedF16;
     if constexpr (HAND_PLACED == 0) {
       qk(K_RD, sb);
@@ -894,8 +926,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     }
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
-        store_v(V_WR);
-        dma_wait_all();
+        finish_tile(V_WR, true);
       } else {
         dma_wait_keep<2 * NDMA>();  // K(j+2), V(j+1) and everything older have landed; the last two iterations' copies fly on
       }
@@ -936,9 +967,9 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
   // an odd fast tile left (j is even here): one more fast iteration instead of a generic one (+11 % at C2, where the
-  // generic body otherwise takes 2 of 32 tiles).  Not for the register-staged bf16 V variants: the third copy of the
-  // fast body pushes them into scratch.
-  if constexpr (!V_BF16 && !abl::kNoOddFast) {
+  // generic body otherwise takes 2 of 32 tiles).  Not for the register-staged bf16 V variants (head_dim 128): the third copy
+  // of the fast body pushes them into scratch.
+  if constexpr (!V_REG && !abl::kNoOddFast) {
     if (j < n_fast) {
       fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
       s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
@@ -969,16 +1000,14 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     }
     softmax_pv(j, j % RING, s_cur, sc0, sc1, std::true_type{});
     if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
-    if (j + 1 < ntiles) store_v((j + 1) & 1);
-    dma_wait_all();
+    finish_tile((j + 1) & 1, j + 1 < ntiles);
     __syncthreads();
     s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
     sc0 = nsc0; sc1 = nsc1;
   }
   for (; j < ntiles; ++j) {
     stage_generic(j);
-    if (j + 1 < ntiles) store_v((j + 1) & 1);
-    dma_wait_all();
+    finish_tile((j + 1) & 1, j + 1 < ntiles);
     __syncthreads();
   }
 

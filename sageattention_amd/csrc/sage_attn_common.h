@@ -73,16 +73,15 @@ __device__ __forceinline__ float swap_sum(float x) {
 // +16*l), `rsrc` = buffer descriptor (4 uniform dwords), `voffset` per lane, `soffset` uniform.
 __device__ __forceinline__ void lds_dma16(v4i rsrc, unsigned lds_off, int voffset, int soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  unsigned keep;
+  // M0 (the LDS base of the copy) is declared clobbered instead of saved and restored around the instruction: two scalar
+  // moves less per copy (+0.2 ... +2 %, most on the short head_dim-64 tiles)
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "buffer_load_dwordx4 %0, %1, %3 offen lds"
+      :
       : "v"(voffset), "s"(rsrc), "s"(lds_off), "s"(soffset)
-      : "memory");
+      : "memory", "m0");
 #endif
 }
 // counted form: wait until at most N of the wave's vector-memory operations are outstanding (they complete in order)

@@ -13,18 +13,21 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--data", default="randn", choices=["randn", "zeros"], help="zeros: DVFS probe (cdna guide rule 25)")
 ap.add_argument("--pv", default="fp16", choices=["fp16", "fp8"])
+ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="element type of q/k/v/o (bf16: the kernel converts V tiles to fp16 on the fly)")
 ap.add_argument("--share-kv", action="store_true", help="latency probe: every head reads the K/V of head 0 (stride 0): all tiles L2 hits")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
                       "c2c": (4, 32, 2048, 64, True), "c16k": (2, 32, 16384, 128, False),
                       "d64_8k": (4, 32, 8192, 64, False), "c3s": (1, 32, 8192, 128, False), "c3xs": (1, 8, 8192, 128, False),
-                      "c3l": (8, 32, 8192, 128, False),
+                      "c3l": (8, 32, 8192, 128, False), "d128_1k": (16, 32, 1024, 128, False), "d128_2kc": (8, 32, 2048, 128, True),
                       "c4": (4, 32, 16384, 128, True)}[a.wl]
 torch.manual_seed(0)
-q = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
-k = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
-v = torch.randn(B, H, N, D, dtype=torch.float16, device="cuda")
+DT = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+EL = 0 if a.dtype == "fp16" else 1   # SAGE_F16 / SAGE_BF16
+q = torch.randn(B, H, N, D, dtype=DT, device="cuda")
+k = torch.randn(B, H, N, D, dtype=DT, device="cuda")
+v = torch.randn(B, H, N, D, dtype=DT, device="cuda")
 if a.data == "zeros":
     q.zero_(); k.zero_(); v.zero_()
 km = sa.quant.k_mean(k)
@@ -52,12 +55,12 @@ st = torch.cuda.current_stream().cuda_stream
 def run(l, nw):
     l.sage_set_tuning(0, nw)
     if a.pv == "fp8":
-        r = l.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, L.desc(o, "HND"), 0, qs.data_ptr(),
+        r = l.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, L.desc(o, "HND"), EL, qs.data_ptr(),
                                       ks.data_ptr(), vs.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
                                       D ** -0.5, 0, st)
         assert r == 0, r
         return
-    r = l.sage_attn_qk_int8_pv_f16(L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(v, "HND"), 0, L.desc(o, "HND"), 0,
+    r = l.sage_attn_qk_int8_pv_f16(L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(v, "HND"), EL, L.desc(o, "HND"), EL,
                                    qs.data_ptr(), ks.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
                                    D ** -0.5, 0, st)
     assert r == 0, r
