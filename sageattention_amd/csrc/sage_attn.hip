@@ -29,7 +29,7 @@ constexpr int attn_ring_slots(int D, int nwaves, bool pv_fp8) { return (pv_fp8 &
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
 template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8, bool HAS_MASK>
-__global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 3) ? 3 : SAGE_MINWAVES) void attn_i8_kernel(const AttnParams p) {
   static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
   static_assert(!HAS_MASK || (!CAUSAL && !PV_FP8 && !V_BF16), "attn_mask: non-causal fp16-PV operator, fp16 V");
   constexpr int T = NWAVES * 64;
@@ -99,11 +99,13 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   const int q0 = qb * QB + wave * 32;
   const int row = q0 + r;
   const int rowc = min(row, M_ - 1);
+  // the lane's row / key-half as the masked tiles and the epilogue see them: re-derived from the lane id after the fast loop
+  // (below), so that neither they nor the output addresses built from them occupy registers while it runs
+  int row_l = row, hh_l = hh;
 
   // ---- Q^T fragments (B operand), resident for the whole kernel, and the per-row q scale
   v4i qf[KS];
   float qsc;
-  float lse_corr = 0.f;
   if (p.q_f16 == nullptr) {
     const int8_t* qp = p.q + q_boff + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
 #pragma unroll
@@ -151,7 +153,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         }
       }
     amax = swap_max(amax);  // the other half of the row
-    lse_corr = swap_sum(dot);
+    // LSE correction q . k_mean of the row: parked in the caller's LSE slot of this row until the epilogue (a register that
+    // lives through the whole tile loop costs the head_dim-64 FP8 variants their third wave per SIMD)
+    const float lse_corr = swap_sum(dot);
+    if (p.lse && hh == 0 && valid) p.lse[((int64_t)b * p.Hq + h) * M_ + row] = lse_corr;
     const bool triton = p.qgran == SAGE_GRAN_PER_THREAD;
     if (triton) {  // rows with equal r % 8 inside the 32-row block (quant_per_thread.py:27-36)
       amax = fmaxf(amax, __shfl_xor(amax, 8));
@@ -324,18 +329,20 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   };
 
   // ---- lane-constant LDS read offsets
-  int k_rd[KS];  // K A-fragment: row r (+32*mt via immediate), chunk 2*ks+hh
+  // (pointers that already include the K / V region base: the fast loops and the generic body then share ONE register per
+  // offset; with integer offsets hipcc kept `base + offset` and `offset` as two live values)
+  const char* k_rd[KS];  // K A-fragment: row r (+32*mt via immediate), chunk 2*ks+hh
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * D + (((2 * ks + hh) ^ k_swz<D>(r)) << 4);
-  int v_rd8[2];  // fp8: V^T row r (+32*dt immediate), 16-B chunks 2*hh and 2*hh+1
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = k_lds + (r * D + (((2 * ks + hh) ^ k_swz<D>(r)) << 4));
+  const char* v_rd8[2];  // fp8: V^T row r (+32*dt immediate), 16-B chunks 2*hh and 2*hh+1
 #pragma unroll
-  for (int c = 0; c < 2; ++c) v_rd8[c] = r * 64 + (((2 * hh + c) ^ ((r >> 2) & 3)) << 4);
-  int v_rd[DT];  // fp16: V^T fragment via tr-read: row 4*hh + q4 (+32*mt+16*s(+8) immediate), window dt
+  for (int c = 0; c < 2; ++c) v_rd8[c] = v_lds + (r * 64 + (((2 * hh + c) ^ ((r >> 2) & 3)) << 4));
+  const char* v_rd[DT];  // fp16: V^T fragment via tr-read: row 4*hh + q4 (+32*mt+16*s(+8) immediate), window dt
   {
     const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g = (lane >> 4) & 1;
     const int rv = 4 * hh + q4;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) v_rd[dt] = rv * (2 * D) + ((dt ^ v_win_swz<D>(rv)) << 6) + 32 * g + 8 * p4;
+    for (int dt = 0; dt < DT; ++dt) v_rd[dt] = v_lds + (rv * (2 * D) + ((dt ^ v_win_swz<D>(rv)) << 6) + 32 * g + 8 * p4);
   }
 
   // ---- state
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         if constexpr (abl::kNoQK) {
           s[mt] = bias; s[mt][0] += kbuf + ks;
         } else {
-          const v4i a = *reinterpret_cast<const v4i*>(k_lds + kbuf * KBYTES + mt * 32 * D + k_rd[ks]);
+          const v4i a = *reinterpret_cast<const v4i*>(k_rd[ks] + (kbuf * KBYTES + mt * 32 * D));
           s[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s[mt], 0, 0, 0);
         }
       }
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // sequence end and causal diagonal (the kernels without attn_mask): register e of block mt holds key
   // 64*j + 32*mt + (e&3) + 8*(e>>2) + 4*hh, allowed iff <= min(N-1, row): one compare against a per-lane limit
   auto mask_limit = [&](const int j, v16i (&s)[2]) __attribute__((always_inline)) {
-    const int lim = min(N_ - 1, CAUSAL ? row : 0x7fffffff) - (j << 6) - 4 * hh;
+    const int lim = min(N_ - 1, CAUSAL ? row_l : 0x7fffffff) - (j << 6) - 4 * hh_l;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
           }
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const char* base = v_lds + vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D) + v_rd[dt];
+            const char* base = v_rd[dt] + (vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D));
             const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
             const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
@@ -617,9 +624,9 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       l_run += psum;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const char* base = v_lds + vbuf * VBYTES + dt * 32 * 64;
-        const v4i lo = *reinterpret_cast<const v4i*>(base + v_rd8[0]);
-        const v4i hi = *reinterpret_cast<const v4i*>(base + v_rd8[1]);
+        const int base = vbuf * VBYTES + dt * 32 * 64;
+        const v4i lo = *reinterpret_cast<const v4i*>(v_rd8[0] + base);
+        const v4i hi = *reinterpret_cast<const v4i*>(v_rd8[1] + base);
         v8i a;
         a.s0123 = lo;
         a.s4567 = hi;
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     scales_from(kk_nxt, b0, b1);
     kk_nxt = load_kscales(min(j + 2, ntiles - 1));
     v4i kf_early = qf[0];
-    if constexpr (!abl::kNoLdsK) kf_early = *reinterpret_cast<const v4i*>(k_lds + K_RD * KBYTES + k_rd[0]);
+    if constexpr (!abl::kNoLdsK) kf_early = *reinterpret_cast<const v4i*>(k_rd[0] + K_RD * KBYTES);
     __builtin_amdgcn_sched_barrier(0);
     maybe_rescale(mx_cur);
     if constexpr (!abl::kNoStage) {
@@ -748,21 +755,20 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       // words are computed, and the four P.V MFMAs run beside the row max of S(j+1).
       constexpr int NS = 2 * KS;       // S MFMAs per tile
       constexpr int WPS = 8 / NS;      // P words per S MFMA (1 at head_dim 128, 2 at 64)
-      const char* const kb = k_lds + K_RD * KBYTES;
-      const char* const vb = v_lds + V_RD * VBYTES;
+      constexpr int kb = K_RD * KBYTES, vb = V_RD * VBYTES;  // slot offsets inside the K / V regions
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
-        return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
+        return *reinterpret_cast<const v4i*>(k_rd[i % KS] + (kb + (i / KS) * 32 * D));
       };
       auto s_step = [&](const int i, const v4i a) __attribute__((always_inline)) {
         const int mt = i / KS, ks = i % KS;
         sb[mt] = ks == 0 ? mfma_s_first(a, qf[ks]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], sb[mt], 0, 0, 0);
       };
       auto v_frag8 = [&](const int dt) __attribute__((always_inline)) -> v8i {
-        const char* base = vb + dt * 32 * 64;
+        const int base = vb + dt * 32 * 64;
         v8i a;
-        a.s0123 = *reinterpret_cast<const v4i*>(base + v_rd8[0]);
-        a.s4567 = *reinterpret_cast<const v4i*>(base + v_rd8[1]);
+        a.s0123 = *reinterpret_cast<const v4i*>(v_rd8[0] + base);
+        a.s4567 = *reinterpret_cast<const v4i*>(v_rd8[1] + base);
         return a;
       };
       v8i pb;
@@ -827,16 +833,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
       // the row max of S(j+1) runs beside the last quarter's MFMAs.  sched_barrier(0) pins each group.
       constexpr int NS = 2 * KS, SPR = NS / 4;  // S MFMAs per tile / per region
       constexpr int PPG = 4 / DT;               // P pairs computed beside one P.V MFMA
-      const char* const kb = k_lds + K_RD * KBYTES;
-      const char* const vb = v_lds + V_RD * VBYTES;
+      constexpr int kb = K_RD * KBYTES, vb = V_RD * VBYTES;  // slot offsets inside the K / V regions
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
         if constexpr (abl::kNoLdsK) return qf[i % KS];
-        else return *reinterpret_cast<const v4i*>(kb + (i / KS) * 32 * D + k_rd[i % KS]);
+        else return *reinterpret_cast<const v4i*>(k_rd[i % KS] + (kb + (i / KS) * 32 * D));
       };
       auto v_frag = [&](const int q, const int dt) __attribute__((always_inline)) -> v8h {
         if constexpr (abl::kNoLdsV) return __builtin_bit_cast(v8h, qf[(q + dt) % KS]);
-        const char* base = vb + 16 * q * (2 * D) + v_rd[dt];
+        const char* base = v_rd[dt] + (vb + 16 * q * (2 * D));
         const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
         const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));
         v8h a;
@@ -978,6 +983,12 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
     }
   }
   }
+  {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    row_l = q0 + (ln & 31);
+    hh_l = ln >> 5;
+  }
   // generic body (masked / last tiles) and, for causal waves that are done early, staging-only iterations: runtime slots,
   // every copy drained (vmcnt(0)) -- the four-slot ring keeps its copy COUNT per iteration constant here as well
   auto stage_generic = [&](const int jj) __attribute__((always_inline)) {
@@ -1016,15 +1027,15 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
   const float l_tot = swap_sum(l_run);
   const float inv = 1.0f / l_tot;
-  if (row < M_) {
-    uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row * p.osn;
+  if (row_l < M_) {
+    uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row_l * p.osn;
     auto store_rows = [&](auto has_vm) __attribute__((always_inline)) {
       const float* vmp = p.v_mean + ((int64_t)b * p.Hk + hk) * D;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+          const int d0 = 32 * dt + 8 * g4 + 4 * hh_l;
           float x[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = acc_o[dt][4 * g4 + e] * inv;
@@ -1048,9 +1059,10 @@ __global__ __launch_bounds__(NWAVES * 64, SAGE_MINWAVES) void attn_i8_kernel(con
         }
     };
     if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
-    if (p.lse && hh == 0) {
+    if (p.lse && hh_l == 0) {
       const float lse2 = m_run + log2f(l_tot) - kPOff;  // base 2, scaled + smoothed logits (…sm80.cu:657-668)
-      p.lse[((int64_t)b * p.Hq + h) * M_ + row] = p.q_f16 ? lse2 / 1.44269504f + lse_corr * p.sm_scale : lse2;
+      float* const slot = p.lse + ((int64_t)b * p.Hq + h) * M_ + row_l;
+      *slot = p.q_f16 ? lse2 / 1.44269504f + *slot * p.sm_scale : lse2;
     }
   }
 }
