@@ -972,9 +972,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
     fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
   // an odd fast tile left (j is even here): one more fast iteration instead of a generic one (+11 % at C2, where the
-  // generic body otherwise takes 2 of 32 tiles).  Not for the register-staged bf16 V variants (head_dim 128): the third copy
-  // of the fast body pushes them into scratch.
-  if constexpr (!V_REG && !abl::kNoOddFast) {
+  // generic body otherwise takes 2 of 32 tiles).
+  if constexpr (!abl::kNoOddFast) {
     if (j < n_fast) {
       fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
       s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];

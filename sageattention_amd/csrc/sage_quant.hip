@@ -123,14 +123,33 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   }
 
   __shared__ unsigned int gmax[64];
+  __shared__ __attribute__((aligned(16))) float mpart[16][D];  // chunk sums of the mean (mean_part form: S <= 16 <= RPP)
   if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
+
+  // the block's rows first: everything below overlaps with this one trip to HBM
+  const uint16_t* xbase = p.x + x_boff + h * p.xsh + tc * 8;
+  float xf[NP][8];
+  uint4 raw[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int row = blk * BLK + i * RPP + tr;
+    raw[i] = make_uint4(0, 0, 0, 0);
+    if (row < N_) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xsn);
+  }
+  // mean_part: thread row s fetches chunk s (ONE round trip to L2 for all S chunks instead of S dependent ones: at 2048
+  // rows the quantizer spent more time on these than on its block), LDS hands every thread all chunks
+  if (p.mean_part && tr < p.S) {
+    const float* pp = p.mean_part + (((int64_t)b * H + h) * p.S + tr) * D + tc * 8;
+    *reinterpret_cast<float4*>(&mpart[tr][tc * 8]) = *reinterpret_cast<const float4*>(pp);
+    *reinterpret_cast<float4*>(&mpart[tr][tc * 8 + 4]) = *reinterpret_cast<const float4*>(pp + 4);
+  }
+  __syncthreads();  // gmax zeroed, mpart filled
 
   float mean_f[8];
   if (p.mean_part) {
     float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const float* pp = p.mean_part + ((int64_t)b * H + h) * p.S * D + tc * 8;
     for (int s_ = 0; s_ < p.S; ++s_) {  // chunk order, as k_mean_final_kernel
-      const float4 a = *reinterpret_cast<const float4*>(pp + s_ * D), c = *reinterpret_cast<const float4*>(pp + s_ * D + 4);
+      const float4 a = *reinterpret_cast<const float4*>(&mpart[s_][tc * 8]), c = *reinterpret_cast<const float4*>(&mpart[s_][tc * 8 + 4]);
       sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w; sum[4] += c.x; sum[5] += c.y; sum[6] += c.z; sum[7] += c.w;
     }
     uint32_t w[4];
@@ -152,17 +171,6 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
     const uint4 ud = *reinterpret_cast<const uint4*>(p.dot_vec + ((int64_t)b * Hk + h / p.dot_group) * D + tc * 8);
     unpack8<BF16>(ud, dvec);
   }
-
-  const uint16_t* xbase = p.x + x_boff + h * p.xsh + tc * 8;
-  float xf[NP][8];
-  uint4 raw[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int row = blk * BLK + i * RPP + tr;
-    raw[i] = make_uint4(0, 0, 0, 0);
-    if (row < N_) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xsn);
-  }
-  __syncthreads();  // gmax zeroed
 
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -333,6 +341,7 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   if (gran == SAGE_GRAN_PER_BLOCK) warp = blk;
   if ((warp != 16 && warp != 32 && warp != 64 && warp != 128) || blk % warp != 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (mean && !aligned16(mean)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (mean_part && (S < 1 || S > 16 || !aligned16(mean_part))) return SAGE_ERR_INVALID_ARGUMENT;  // mpart[16][D] in the kernel
   if ((lse_dot_vec != nullptr) != (lse_dot != nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
   if (lse_dot_vec && (dot_group <= 0 || H % dot_group != 0 || !aligned16(lse_dot_vec))) return SAGE_ERR_INVALID_ARGUMENT;
   const int nblk = (N + blk - 1) / blk;
