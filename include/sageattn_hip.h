@@ -257,6 +257,16 @@ int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float*
 int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H, int N, int D, const sage_tensor* out,
                         float* scale, void* km, int gran, int rounding, void* workspace, sage_stream_t stream);
 
+/* The whole K/V side of the FP8-PV operator's pre-pass as ONE call: km + INT8 K (as sage_k_smooth_quant) and the FP8 V^T
+ * with its per-channel scale (as sage_quant_v_fp8 with v_mean = NULL, i.e. smooth_v = False), k and v of equal shape
+ * [B,H,N,D].  Up to 4096 rows it runs as two launches (K and V column statistics per chunk; both quantizers, each finishing
+ * its own statistics) instead of five; longer sequences run the two separate entry points.  Results are bit-identical to
+ * those either way.  Replaces core.py:612 + :621-624 (K half) + per_channel_fp8 (quant.py:225-322, fused.cu:262-427). */
+size_t sage_kv_prepare_fp8_workspace_bytes(int B, int H, int N, int D);
+int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, int dtype, int B, int H, int N, int D,
+                        const sage_tensor* k_int8, float* k_scale, void* km, int gran, int rounding,
+                        const sage_tensor* v_fp8, float* v_scale, float scale_max, void* workspace, sage_stream_t stream);
+
 /* ==== sequence-parallel building blocks (new: the reference has no parallelism code; its hook is
  * return_lse, core.py:122-124, and its multi-GPU launcher delegates to xDiT, example/parallel_sageattn_cogvideo.py:40-52).
  * With ONE smoothing mean and ONE V scale for the whole sequence (statistics exchanged first: a few KB), the quantized

@@ -67,6 +67,9 @@ SIGNATURES = {
     "sage_set_tuning": (c_int, [c_int, c_int]),
     "sage_k_smooth_quant": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                     c_void_p]),
+    "sage_kv_prepare_fp8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sage_kv_prepare_fp8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, c_void_p, c_int, c_int, _P,
+                                    c_void_p, c_float, c_void_p, c_void_p]),
     "sage_attn_qk_int8_pv_f16_kvtiles": (c_int, [_P, _P, _P, c_int, _P, c_int, c_void_p, c_void_p, _PL, c_void_p,
                                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                  c_float, c_void_p]),

@@ -11,15 +11,9 @@
 // position pos makes every A fragment 32 contiguous bytes of a V^T row.  This plays the role of the reference's
 // NVIDIA-fragment permutation (quant.py:234) for the gfx950 fragment; the layout is private to this library.
 #include "sage_common.h"
+#include "sage_fp8_kernels.h"
 
 namespace sage {
-
-constexpr int VQ_ROWS = 256;  // tokens per workgroup in pass 1
-
-__host__ __device__ __forceinline__ int mfma_order_token(int pos) {
-  const int h = pos >> 5, j = pos & 31;
-  return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h;
-}
 
 template <int D, bool BF16>
 __global__ __launch_bounds__(256) void v_stats_partial_kernel(const uint16_t* __restrict__ v, int64_t sb, int64_t sh,
@@ -85,59 +79,23 @@ __global__ void v_stats_final_kernel(const float* __restrict__ part, int S, int 
   coef[(bh * 2 + 1) * D + d] = scale_max / amax;
 }
 
-// Pass 2: quantize + transpose.  A thread owns 8 channels of FOUR consecutive tokens: in MFMA order (see the header) tokens
-// 4g .. 4g+3 sit at four consecutive positions, so the thread packs them into one dword per channel and the [d][pos]
-// image in LDS is written with 8 ds_write_b32 per thread (the first version wrote single bytes, 16-way bank conflicted:
-// 0.24 ms at C4 against 0.16 now).  Rows of the image are 64 B; every group of 8 rows is padded by 16 B, which spreads
-// the 16 channel groups of a wave over 8 banks (2-way is free for ds_write_b32) and keeps the 16-B reads aligned.
+// Pass 2: quantize + transpose (body: sage_fp8_kernels.h)
 template <int D, bool BF16>
 __global__ __launch_bounds__(256) void v_quant_transpose_kernel(const uint16_t* __restrict__ v, int64_t sb, int64_t sh,
                                                                 int64_t sn, int N, const float* __restrict__ coef,
                                                                 uint8_t* __restrict__ out, int64_t ob, int64_t oh,
                                                                 int64_t od, int64_t o_tile) {
-  constexpr int TPR = D / 8;        // threads per token row
-  constexpr int TG = 256 / TPR;     // token groups (of 4 tokens) per workgroup
-  constexpr int BLKS = TG / 16;     // 64-token blocks per workgroup: 1 (head_dim 128) or 2 (64)
-  constexpr int IMG = D * 16 + (D / 8) * 4;  // dwords per block image
+  using G = VQuantGeom<D>;
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
-  const int tg = threadIdx.x / TPR, tc = threadIdx.x % TPR;
-  const int bi = tg / 16, t0 = 4 * (tg % 16);
-  const int blk = blockIdx.x * BLKS + bi;
-  __shared__ __attribute__((aligned(16))) uint32_t tile[BLKS][IMG];
+  const int tc = threadIdx.x % G::TPR;
+  __shared__ __attribute__((aligned(16))) uint32_t tile[G::BLKS * G::IMG];
   float mean[8], rcp[8];
   {
     const float* cf = coef + (((int64_t)b * H + h) * 2) * D + tc * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mean[j] = cf[j]; rcp[j] = cf[D + j]; }
   }
-  float x[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = blk * 64 + t0 + i;
-    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < N) unpack8<BF16>(*reinterpret_cast<const uint4*>(v + b * sb + h * sh + (int64_t)row * sn + tc * 8), f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[i][j] = row < N ? (f[j] - mean[j]) * rcp[j] : 0.f;  // pad columns are exact zeros
-  }
-  // token t = 32*mt + (reg&3) + 8*(reg>>2) + 4*hh  ->  pos = 32*hh + 16*mt + reg; tokens t0..t0+3 differ in reg&3 only
-  const int mt = t0 >> 5, w0 = t0 & 31, hh = (w0 >> 2) & 1;
-  const int pos_dw = 8 * hh + 4 * mt + (w0 >> 3);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0][j], x[1][j], 0, false);  // OCP e4m3fn, RNE, saturating
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[2][j], x[3][j], pk, true);
-    const int d = tc * 8 + j;
-    tile[bi][d * 16 + 4 * (d >> 3) + pos_dw] = (uint32_t)pk;
-  }
-  __syncthreads();
-  // D rows x 64 B per block: 4 x 16 B chunks per row
-  for (int c = threadIdx.x; c < BLKS * D * 4; c += 256) {
-    const int bo = c / (D * 4), cc = c % (D * 4), d = cc >> 2, ch = cc & 3;
-    const int ob_blk = blockIdx.x * BLKS + bo;
-    if (ob_blk * 64 >= N) continue;
-    const uint4 u = *reinterpret_cast<const uint4*>(&tile[bo][d * 16 + 4 * (d >> 3) + ch * 4]);
-    *reinterpret_cast<uint4*>(out + b * ob + h * oh + (int64_t)d * od + ob_blk * o_tile + ch * 16) = u;
-  }
+  v_quant_transpose_body<D, BF16>(v, sb, sh, sn, N, mean, rcp, out, ob, oh, od, o_tile, blockIdx.x, h, b, tile);
 }
 
 // raw per-channel statistics (max, min, sum) of one tensor: second level of v_stats_partial_kernel

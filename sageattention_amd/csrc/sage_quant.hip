@@ -7,6 +7,7 @@
 // Every thread moves 16 B per load (8 fp16/bf16), the widest coalesced access on CDNA4.
 // Compiled with -ffp-contract=off: the integer outputs must match the oracle bit for bit.
 #include "sage_common.h"
+#include "sage_fp8_kernels.h"
 
 namespace sage {
 
@@ -15,12 +16,13 @@ namespace sage {
 // ------------------------------------------------------------------------------------------------
 constexpr int KMEAN_ROWS = 256;  // rows per workgroup in pass 1
 
+// chunk s (KMEAN_ROWS rows) of head (b, h) of H: column sums -> part[b][h][s][D]; `red`: 256/(D/8) x (D+1) floats of LDS
 template <int D, bool BF16>
-__global__ __launch_bounds__(256) void k_mean_partial_kernel(const uint16_t* __restrict__ k, int64_t sb, int64_t sh,
-                                                             int64_t sn, int N, float* __restrict__ part, int S) {
+__device__ __forceinline__ void k_mean_partial_body(const uint16_t* __restrict__ k, int64_t sb, int64_t sh, int64_t sn, int N,
+                                                    float* __restrict__ part, int S, int s, int h, int b, int H,
+                                                    float (*red)[D + 1]) {
   constexpr int TPR = D / 8;       // threads per row
   constexpr int RPP = 256 / TPR;   // rows per pass
-  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
   const uint16_t* base = k + b * sb + h * sh + tc * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -36,15 +38,21 @@ __global__ __launch_bounds__(256) void k_mean_partial_kernel(const uint16_t* __r
       for (int j = 0; j < 8; ++j) acc[j] += f[j];
     }
   }
-  __shared__ float red[RPP][D + 1];
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[tr][tc * 8 + j] = acc[j];
   __syncthreads();
   if (threadIdx.x < D) {
     float sum = 0.f;
     for (int r = 0; r < RPP; ++r) sum += red[r][threadIdx.x];  // fixed order
-    part[(((int64_t)b * gridDim.y + h) * S + s) * D + threadIdx.x] = sum;
+    part[(((int64_t)b * H + h) * S + s) * D + threadIdx.x] = sum;
   }
+}
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void k_mean_partial_kernel(const uint16_t* __restrict__ k, int64_t sb, int64_t sh,
+                                                             int64_t sn, int N, float* __restrict__ part, int S) {
+  __shared__ float red[256 / (D / 8)][D + 1];
+  k_mean_partial_body<D, BF16>(k, sb, sh, sn, N, part, S, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, red);
 }
 
 template <bool BF16>
@@ -103,14 +111,14 @@ __device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int wa
   return is_key ? w * 4 + ((lr & 7) >> 1) : w * 8 + (lr & 7);
 }
 
+// block `blk` (BLK rows) of head (b, h) of H.  LDS: gmax = 64 dwords, mpart = 16 x D floats (16-byte aligned)
 template <int D, int BLK, bool BF16>
-__global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p) {
+__device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const int blk, const int h, const int b, const int H,
+                                                   unsigned int* gmax, float (*mpart)[D]) {
   constexpr int TPR = D / 8;
   constexpr int RPP = 256 / TPR;
   constexpr int NP = BLK / RPP;
   static_assert(NP >= 1, "block too small");
-  const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int H = gridDim.y;
   const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
   int N_ = p.N;
   int64_t x_boff = b * p.xsb, o_boff = b * p.osb;
@@ -122,8 +130,6 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
     o_boff = (int64_t)lo * p.osn;
   }
 
-  __shared__ unsigned int gmax[64];
-  __shared__ __attribute__((aligned(16))) float mpart[16][D];  // chunk sums of the mean (mean_part form: S <= 16 <= RPP)
   if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
 
   // the block's rows first: everything below overlaps with this one trip to HBM
@@ -262,6 +268,109 @@ __global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p)
   }
 }
 
+template <int D, int BLK, bool BF16>
+__global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p) {
+  __shared__ unsigned int gmax[64];
+  __shared__ __attribute__((aligned(16))) float mpart[16][D];  // chunk sums of the mean (mean_part form: S <= 16 <= RPP)
+  quant_qk_int8_body<D, BLK, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gmax, mpart);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused K/V pre-pass of the FP8-PV operator for sequences of at most 16 chunks (4096 rows): TWO launches instead of five
+// (k_mean_partial, quantizer | v_stats_partial, v_stats_final, v_quant_transpose).  Every kernel below is bandwidth- or
+// latency-bound and fills the chip on its own, so what the fusion saves is three launch boundaries and the ramp / tail of
+// three kernels, and the VALU-heavy K quantizer shares the CUs with the bandwidth-bound V quantizer.
+//   launch A  workgroups [0, S): K column sums per chunk;  [S, 2S): V per-channel max|v| per chunk
+//   launch B  workgroups [0, nblk_k): K quantizer (finishes the mean itself);  the rest: V quantizer + transpose (finishes
+//             max|v| itself, block 0 stores v_scale)
+// Without V smoothing only max|v| is needed, which does not depend on the order of the reduction: bit-identical to
+// sage_k_smooth_quant + sage_quant_v_fp8(v_mean = null).
+// ------------------------------------------------------------------------------------------------
+struct VPrepParams {
+  const uint16_t* v;
+  int64_t sb, sh, sn;
+  uint8_t* out;
+  int64_t ob, oh, od, o_tile;
+  float* v_scale;      // [B,H,D]
+  const float* part;   // [B,H,S,D] max|v| per chunk
+  float scale_max;
+};
+
+template <int D, bool BF16>
+__device__ __forceinline__ void v_amax_partial_body(const uint16_t* __restrict__ v, int64_t sb, int64_t sh, int64_t sn, int N,
+                                                    float* __restrict__ part, int S, int s, int h, int b, int H,
+                                                    float (*red)[D + 1]) {
+  constexpr int TPR = D / 8, RPP = 256 / TPR;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
+  const uint16_t* base = v + b * sb + h * sh + tc * 8;
+  float am[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rows in [N, ceil16(N)) count as zeros (fused.cu:335): the same as starting at 0
+#pragma unroll 4
+  for (int i = 0; i < VQ_ROWS / RPP; ++i) {
+    const int row = s * VQ_ROWS + i * RPP + tr;
+    if (row < N) {
+      float f[8];
+      unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) am[j] = fmaxf(am[j], fabsf(f[j]));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tr][tc * 8 + j] = am[j];
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float a = red[0][threadIdx.x];
+    for (int r = 1; r < RPP; ++r) a = fmaxf(a, red[r][threadIdx.x]);
+    part[(((int64_t)b * H + h) * S + s) * D + threadIdx.x] = a;
+  }
+}
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void kv_partial_kernel(const uint16_t* __restrict__ k, int64_t ksb, int64_t ksh, int64_t ksn,
+                                                         const uint16_t* __restrict__ v, int64_t vsb, int64_t vsh, int64_t vsn,
+                                                         int N, float* __restrict__ kpart, float* __restrict__ vpart, int S) {
+  static_assert(KMEAN_ROWS == VQ_ROWS, "one chunk size for both tensors");
+  __shared__ float red[256 / (D / 8)][D + 1];
+  const int x = blockIdx.x;
+  if (x < S) k_mean_partial_body<D, BF16>(k, ksb, ksh, ksn, N, kpart, S, x, blockIdx.y, blockIdx.z, gridDim.y, red);
+  else v_amax_partial_body<D, BF16>(v, vsb, vsh, vsn, N, vpart, S, x - S, blockIdx.y, blockIdx.z, gridDim.y, red);
+}
+
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void kv_quant_kernel(const QuantParams p, const VPrepParams q, const int nblk_k) {
+  using G = VQuantGeom<D>;
+  __shared__ unsigned int gmax[64];
+  __shared__ __attribute__((aligned(16))) float exch[16][D];  // chunk partials of this head: K sums or V max|v|
+  __shared__ __attribute__((aligned(16))) uint32_t tile[G::BLKS * G::IMG];
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  if ((int)blockIdx.x < nblk_k) {
+    quant_qk_int8_body<D, 64, BF16>(p, blockIdx.x, h, b, H, gmax, exch);
+    return;
+  }
+  const int bx = blockIdx.x - nblk_k;
+  const int tg = threadIdx.x / G::TPR, tc = threadIdx.x % G::TPR;
+  if (tg < p.S) {  // one round trip for all chunks (S <= 16 <= token groups per workgroup)
+    const float* pp = q.part + (((int64_t)b * H + h) * p.S + tg) * D + tc * 8;
+    *reinterpret_cast<float4*>(&exch[tg][tc * 8]) = *reinterpret_cast<const float4*>(pp);
+    *reinterpret_cast<float4*>(&exch[tg][tc * 8 + 4]) = *reinterpret_cast<const float4*>(pp + 4);
+  }
+  __syncthreads();
+  float mean[8], rcp[8], vs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float a = exch[0][tc * 8 + j];
+    for (int s_ = 1; s_ < p.S; ++s_) a = fmaxf(a, exch[s_][tc * 8 + j]);
+    mean[j] = 0.f;
+    rcp[j] = q.scale_max / a;   // v_stats_final_kernel
+    vs[j] = a / q.scale_max;
+  }
+  if (bx == 0 && tg == 0) {
+    float* o = q.v_scale + ((int64_t)b * H + h) * D + tc * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(vs[4], vs[5], vs[6], vs[7]);
+  }
+  v_quant_transpose_body<D, BF16>(q.v, q.sb, q.sh, q.sn, p.N, mean, rcp, q.out, q.ob, q.oh, q.od, q.o_tile, bx, h, b, tile);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: sub_mean_f16
 // ------------------------------------------------------------------------------------------------
@@ -331,7 +440,7 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
                       const sage_tensor* out, float* scale, int gran, int is_key, int blk, int warp,
                       float mult, int rounding, const void* lse_dot_vec, int dot_group, float* lse_dot,
                       sage_stream_t stream, const int* cu, int64_t out_blk_stride = 0, const int64_t* scale_strides = nullptr,
-                      const float* mean_part = nullptr, int S = 0, void* km_out = nullptr) {
+                      const float* mean_part = nullptr, int S = 0, void* km_out = nullptr, QuantParams* params_only = nullptr) {
   if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !scale || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
@@ -361,6 +470,7 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   if (out_blk_stride < 0 || (out_blk_stride & 7) || p.ss_blk < gpb) return SAGE_ERR_INVALID_ARGUMENT;
   p.N = N; p.G = nblk * gpb; p.gran = gran; p.is_key = is_key ? 1 : 0; p.warp = warp; p.mult = mult; p.rounding = rounding;
   p.warp_shift = warp == 16 ? 4 : warp == 32 ? 5 : warp == 64 ? 6 : 7;
+  if (params_only) { *params_only = p; return SAGE_OK; }  // validated parameters for a fused launch (sage_kv_prepare_fp8)
   dim3 grid(nblk, H, B);
   hipStream_t st = (hipStream_t)stream;
   launch_begin();
@@ -447,4 +557,57 @@ extern "C" int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H
   if (launch_status() != SAGE_OK) return SAGE_ERR_LAUNCH;
   return quant_impl(k, dtype, B, H, N, D, nullptr, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr,
                     0, nullptr, ws, S, km);
+}
+
+extern "C" size_t sage_kv_prepare_fp8_workspace_bytes(int B, int H, int N, int D) {
+  // the fused form needs 2 x [B,H,S,D] floats; longer sequences run the separate kernels on the same buffer
+  return sage_k_mean_workspace_bytes(B, H, N, D) + sage_quant_v_fp8_workspace_bytes(B, H, N, D);
+}
+
+extern "C" int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, int dtype, int B, int H, int N, int D,
+                                   const sage_tensor* k_int8, float* k_scale, void* km, int gran, int rounding,
+                                   const sage_tensor* v_fp8, float* v_scale, float scale_max, void* workspace,
+                                   sage_stream_t stream) {
+  if (!km || !workspace || !v_scale || !(scale_max > 0.f)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (gran != SAGE_GRAN_PER_BLOCK && gran != SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
+  if (!tensor_ok(k, 8) || !tensor_ok(v, 8) || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
+  if (!v_fp8 || !v_fp8->data || !aligned16(v_fp8->data) || v_fp8->stride_b % 16 || v_fp8->stride_h % 16 || v_fp8->stride_n % 16)
+    return SAGE_ERR_INVALID_ARGUMENT;
+  if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
+  if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
+  const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
+  if (S > 16) {  // long sequences: the launches are a small share, and the quantizers finish their statistics separately
+    const int st = sage_k_smooth_quant(k, dtype, B, H, N, D, k_int8, k_scale, km, gran, rounding, workspace, stream);
+    if (st != SAGE_OK) return st;
+    return sage_quant_v_fp8(v, dtype, B, H, N, D, v_fp8, v_scale, nullptr, scale_max,
+                            (char*)workspace + sage_k_mean_workspace_bytes(B, H, N, D), stream);
+  }
+  float* kpart = (float*)workspace;
+  float* vpart = kpart + (size_t)B * H * S * D;
+  QuantParams p;
+  const int st0 = quant_impl(k, dtype, B, H, N, D, nullptr, k_int8, k_scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr,
+                             stream, nullptr, 0, nullptr, kpart, S, km, &p);
+  if (st0 != SAGE_OK) return st0;
+  VPrepParams q;
+  q.v = (const uint16_t*)v->data; q.sb = v->stride_b; q.sh = v->stride_h; q.sn = v->stride_n;
+  q.out = (uint8_t*)v_fp8->data; q.ob = v_fp8->stride_b; q.oh = v_fp8->stride_h; q.od = v_fp8->stride_n; q.o_tile = 64;
+  q.v_scale = v_scale; q.part = vpart; q.scale_max = scale_max;
+  const int nblk_k = (N + 63) / 64;
+  const int vq_blks = D == 128 ? 1 : 2;  // 64-token blocks per V workgroup (VQuantGeom<D>::BLKS)
+  const int nblk_v = (nblk_k + vq_blks - 1) / vq_blks;
+  hipStream_t st = (hipStream_t)stream;
+  launch_begin();
+  const dim3 ga(2 * S, H, B), gb(nblk_k + nblk_v, H, B);
+  const uint16_t* kp = (const uint16_t*)k->data;
+#define LA(DD, BF)                                                                                                          \
+  hipLaunchKernelGGL((kv_partial_kernel<DD, BF>), ga, dim3(256), 0, st, kp, k->stride_b, k->stride_h, k->stride_n, q.v, q.sb, \
+                     q.sh, q.sn, N, kpart, vpart, S)
+#define LB(DD, BF) hipLaunchKernelGGL((kv_quant_kernel<DD, BF>), gb, dim3(256), 0, st, p, q, nblk_k)
+  const bool bf = dtype == SAGE_BF16;
+  if (D == 64) { if (bf) LA(64, true); else LA(64, false); } else { if (bf) LA(128, true); else LA(128, false); }
+  if (launch_status() != SAGE_OK) return SAGE_ERR_LAUNCH;
+  if (D == 64) { if (bf) LB(64, true); else LB(64, false); } else { if (bf) LB(128, true); else LB(128, false); }
+#undef LA
+#undef LB
+  return launch_status();
 }

@@ -85,6 +85,34 @@ def k_smooth_quant(k: torch.Tensor, tensor_layout: str, gran: int, rounding: int
     return out, scale, km
 
 
+def kv_prepare_fp8(k: torch.Tensor, v: torch.Tensor, tensor_layout: str, gran: int, rounding: int, scale_max: float = 448.0):
+    """The K/V side of the FP8-PV operator's pre-pass as one call of the library (sage_kv_prepare_fp8): ``k_smooth_quant(k)``
+    and ``per_channel_fp8(v, smooth_v=False)``, bit-identical to them, two launches instead of five up to 4096 rows.
+    Returns (k_int8, k_scale, km, v_fp8, v_scale)."""
+    B, H, N, D = L.dims(k, tensor_layout)
+    assert L.dims(v, tensor_layout) == (B, H, N, D), "k and v must have the same shape"
+    npad = (N + 63) // 64 * 64
+    if tensor_layout == "HND":
+        k8 = torch.empty(k.shape, dtype=torch.int8, device=k.device)
+        v8 = torch.empty((B, H, D, npad), dtype=torch.float8_e4m3fn, device=v.device)
+        vd = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(1), v8.stride(2))
+    else:
+        k8 = torch.empty((B, H, N, D), dtype=torch.int8, device=k.device).transpose(1, 2)
+        v8 = torch.empty((B, D, H, npad), dtype=torch.float8_e4m3fn, device=v.device)
+        vd = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(2), v8.stride(1))
+    G = (N + 63) // 64 * (4 if gran == L.GRAN_PER_THREAD else 1)
+    ks = torch.empty((B, H, G), dtype=torch.float32, device=k.device)
+    km = torch.empty((B, H, D), dtype=k.dtype, device=k.device)
+    v_scale = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
+    lib = L.lib()
+    ws = torch.empty(max(1, lib.sage_kv_prepare_fp8_workspace_bytes(B, H, N, D) // 4), dtype=torch.float32, device=k.device)
+    L.check(lib.sage_kv_prepare_fp8(L.desc(k, tensor_layout), L.desc(v, tensor_layout), L.dtype_code(k.dtype), B, H, N, D,
+                                    L.desc(k8, tensor_layout), ks.data_ptr(), km.data_ptr(), gran, rounding, vd,
+                                    v_scale.data_ptr(), float(scale_max), ws.data_ptr(), L.stream_ptr(k.device)),
+            "sage_kv_prepare_fp8")
+    return k8, ks, km, v8, v_scale
+
+
 def per_block_int8(q, k, km=None, BLKQ=128, BLKK=64, sm_scale=None, tensor_layout="HND", rounding="cuda"):
     """quant.py:23-104.  ``rounding="triton"`` gives the numerics of triton/quant_per_block.py:48-101."""
     D = q.size(-1)

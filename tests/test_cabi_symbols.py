@@ -76,6 +76,10 @@ def test_sequence_parallel_entry_points_validate_arguments(built_lib):
     assert l.sage_quant_k_int8_kvtiles(t, 0, 1, 1, 64, 64, None, t, 4096, 16, st3, 2, 0, None) == -1      # per_warp is a Q granularity
     assert l.sage_quant_v_fp8_apply(t, 0, 1, 1, 64, 64, t, 24, 16, None) == -1                            # unaligned tile stride
     assert l.sage_k_smooth_quant(t, 0, 1, 1, 64, 64, t, 16, None, 3, 0, 16, None) == -1                   # km missing
+    assert l.sage_kv_prepare_fp8(t, t, 0, 1, 1, 64, 64, t, 16, None, 3, 0, t, 16, 448.0, 16, None) == -1  # km missing
+    assert l.sage_kv_prepare_fp8(t, t, 0, 1, 1, 64, 96, t, 16, 16, 3, 0, t, 16, 448.0, 16, None) == -2    # head_dim
+    assert l.sage_kv_prepare_fp8(t, t, 0, 1, 1, 64, 64, t, 16, 16, 2, 0, t, 16, 448.0, 16, None) == -1    # per_warp is a Q granularity
+    assert l.sage_kv_prepare_fp8_workspace_bytes(2, 3, 1000, 64) >= 2 * 2 * 3 * 4 * 64 * 4
     op = (C.c_void_p * 1)(16)
     assert l.sage_merge_attn_states_multi_ex(op, op, 1, 0, 16, None, 4, 64, 0.0, None, 0.0, None) == -1   # lse multiplier must be > 0
 

@@ -671,3 +671,28 @@ def test_k_smooth_quant_is_bit_identical_to_mean_plus_quantizer(sa, layout, dt):
             k8, ks, _ = _quant(k, layout, gran, True, 64, 64, 1.0, rnd, mean=km, dense_heads=True)
             k8b, ksb, kmb = k_smooth_quant(k, layout, gran, rnd)
             assert torch.equal(kmb, km) and torch.equal(ksb, ks) and torch.equal(k8b, k8), (B, H, N, D, gran, rnd)
+
+
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_kv_prepare_fp8_is_bit_identical_to_the_separate_quantizers(sa, layout, dt):
+    """sage_kv_prepare_fp8 (K smoothing + INT8 and the FP8 V^T in one call: two launches up to 16 chunks of 256 rows, where
+    both quantizers finish their own statistics; the separate kernels beyond) against sage_k_smooth_quant and
+    sage_quant_v_fp8 without V smoothing: every output bit-identical, ragged / single-row / long shapes, V outliers."""
+    from sageattention_amd import _lib as L
+    from sageattention_amd.quant import k_smooth_quant, kv_prepare_fp8, per_channel_fp8
+    for i, (B, H, N, D) in enumerate([(1, 1, 1, 64), (2, 3, 63, 128), (1, 2, 257, 64), (2, 4, 1000, 128), (1, 5, 4096, 64),
+                                      (2, 2, 4096, 128), (1, 2, 4097, 128), (1, 4, 8192, 64), (3, 2, 2050, 64)]):
+        g = torch.Generator(device="cuda").manual_seed(700 + i)
+        shape = (B, H, N, D) if layout == "HND" else (B, N, H, D)
+        k = (torch.randn(shape, device="cuda", generator=g) * 2 + torch.randn((1, 1, 1, D), device="cuda", generator=g) * 3).to(dt)
+        v = (torch.randn(shape, device="cuda", generator=g) * (1 + 5 * torch.rand((1, 1, 1, D), device="cuda", generator=g))).to(dt)
+        for gran, rnd in ((L.GRAN_PER_THREAD, L.ROUND_TRITON), (L.GRAN_PER_BLOCK, L.ROUND_CUDA)):
+            k8, ks, km = k_smooth_quant(k, layout, gran, rnd)
+            v8, vs, _ = per_channel_fp8(v, tensor_layout=layout, smooth_v=False)
+            k8b, ksb, kmb, v8b, vsb = kv_prepare_fp8(k, v, layout, gran, rnd)
+            assert torch.equal(kmb, km) and torch.equal(ksb, ks) and torch.equal(k8b, k8), (B, H, N, D, gran, rnd)
+            assert torch.equal(vsb, vs), (B, H, N, D)
+            assert v8b.shape == v8.shape and v8b.stride() == v8.stride()
+            # pad columns beyond N are written as zeros by both; compare the raw bytes
+            assert torch.equal(v8b.view(torch.uint8)[..., :N], v8.view(torch.uint8)[..., :N]), (B, H, N, D)
