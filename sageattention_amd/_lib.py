@@ -145,7 +145,14 @@ def dims(t: torch.Tensor, tensor_layout: str):
     raise ValueError(f"Unknown tensor layout: {tensor_layout}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device) -> int:
+    """hipStream_t of torch's current stream on `device` (the raw getter is ~10x cheaper than building a Stream object:
+    4 us of the ~40 us a call costs on the host)."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 
