@@ -83,8 +83,9 @@ def cpu_baseline(D, causal):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (200 for c2, whose step is 0.17 ms: a 4 ms timed "
+                    "region is over before the clocks have settled and reads 15-20 %% low)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 5 (20 for c2)")
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
     ap.add_argument("--gran", default="per_thread", choices=["per_warp", "per_thread"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,6 +138,10 @@ def main():
     variant = args.pv or variant
     N = args.seq or N
     causal = bool(args.causal) if args.causal is not None else causal
+    if args.steps is None:
+        args.steps = 200 if wl == "c2" else 20
+    if args.warmup is None:
+        args.warmup = 20 if wl == "c2" else 5
     torch.manual_seed(0)
 
     if wl == "ring" and use_dist:
