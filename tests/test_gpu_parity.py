@@ -325,6 +325,42 @@ def test_sageattn_dispatch_rule(sa, monkeypatch):
         sa.sageattn(q, k, v)
 
 
+@pytest.mark.parametrize("cfg", [(2, 8, 2048, 64, False, 0), (2, 8, 1000, 64, True, 0), (1, 4, 2115, 64, False, 8), (2, 4, 777, 128, True, 0),
+                                 (1, 8, 1024, 128, False, 4), (1, 2, 63, 64, False, 0), (4, 32, 2048, 64, True, 0)])
+def test_bf16_v_converted_in_the_kernel_equals_v_converted_before(sa, cfg):
+    """core.py:633 converts a bf16 V to fp16 before the kernel; this library converts the V tiles inside the kernel (head_dim 64:
+    in place in LDS by the wave that copied the slice; head_dim 128: in registers on the way to LDS).  Same INT8 operands, V
+    given once as bf16 and once as ``v.to(float16)``: outputs and LSE must agree bit for bit, 20 launches each (the in-place
+    form reads LDS that an asynchronous copy has just written: a missing wait would show as a flicker)."""
+    from sageattention_amd import _lib as L, core
+    B, H, N, D, causal, nw = cfg
+    torch.manual_seed(41)
+    q, k = (torch.randn(B, H, N, D, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    v = (torch.randn(B, H, N, D, device="cuda") * 3).to(torch.bfloat16)
+    km = sa.quant.k_mean(k)
+    q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
+    v16 = v.to(torch.float16)
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(vt, vdt):
+        o = torch.empty(B, H, N, D, dtype=torch.bfloat16, device="cuda")
+        lse = torch.empty(B, H, N, dtype=torch.float32, device="cuda")
+        r = lib.sage_attn_qk_int8_pv_f16(L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(vt, "HND"), vdt, L.desc(o, "HND"), L.SAGE_BF16,
+                                         qs.data_ptr(), ks.data_ptr(), None, lse.data_ptr(), B, H, H, N, N, D, int(causal), 3, 128,
+                                         32, D ** -0.5, 0, st)
+        assert r == 0, r
+        return o, lse
+    lib.sage_set_tuning(0, nw)
+    try:
+        o_ref, l_ref = run(v16, L.SAGE_F16)
+        for _ in range(20):
+            o, l = run(v, L.SAGE_BF16)
+            assert torch.equal(o, o_ref) and torch.equal(l, l_ref), cfg
+    finally:
+        lib.sage_set_tuning(0, 0)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("cfg", [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8")])
 def test_determinism_under_perturbed_timing(sa, cfg, fused):
