@@ -13,12 +13,13 @@ if len(sys.argv) > 2:  # "nofuse": Q quantizer as a separate kernel
     sa.core.FUSE_Q_QUANT = sys.argv[2] != "nofuse"
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 gran = sys.argv[4] if len(sys.argv) > 4 else "per_thread"
+dtype = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == "bf16") else torch.float16  # bf16: in-kernel V conversion
 torch.manual_seed(23)
 big = [torch.randn(4, 32, 8192, 128, dtype=torch.float16, device="cuda") for _ in range(3)]
 cfgs = [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8"),
         (2, 16, 4096, 128, True, "fp16"), (2, 16, 4096, 128, True, "fp8"), (4, 32, 2048, 64, False, "fp16")]
 for (B, H, N, D, causal, pv) in (cfgs if only is None else cfgs[only:only + 1]):
-    q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
+    q, k, v = (torch.randn(B, H, N, D, dtype=dtype, device="cuda") for _ in range(3))
     fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
     o0, l0 = fn(q, k, v, is_causal=causal, return_lse=True, qk_quant_gran=gran)
     nd, first = 0, None
