@@ -104,8 +104,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
   int row_l = row, hh_l = hh;
 
   // ---- Q^T fragments (B operand), resident for the whole kernel, and the per-row q scale
+  // (a lambda: it runs AFTER the first K/V tile copies have been issued, below -- nothing in it depends on them, and with
+  //  one workgroup per CU nobody else hides the latency of its loads; the copies and the Q loads then fly together)
   v4i qf[KS];
   float qsc;
+  auto prepare_q = [&]() __attribute__((always_inline)) {
   if (p.q_f16 == nullptr) {
     const int8_t* qp = p.q + q_boff + h * p.qsh + (int64_t)rowc * p.qsn + 16 * hh;
 #pragma unroll
@@ -171,43 +174,48 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
     const float inv = 127.f / a_c;
     const float rcp_sc = 1.0f / sc;
     // Triton numerics need x/sc correctly rounded before the half-away rounding; as in K1 the reciprocal product is
-    // used unless some value of the wave lands within 2^-14 of a rounding boundary (then the exact division decides)
-    auto quantize = [&](const bool exact) __attribute__((always_inline)) -> bool {
+    // used unless some value of the wave's 8-column chunk lands within 2^-14 of a rounding boundary (then the exact
+    // division decides, for that chunk: ~6 % of the chunks; deciding once for the wave's whole 32 x D block sent
+    // 40 % of the waves through the slow form)
+    const bool rcp_bad = !(fabsf(rcp_sc) < 3.0e38f);
+    auto quant8 = [&](const float (&f)[8], int (&qv)[8], const bool exact) __attribute__((always_inline)) -> bool {
       bool near = false;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        uint32_t w[4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float f[8];
-          unpack(raw[ks][c], f);
-          int qv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (triton) {
-              float y = exact ? f[e] / sc : f[e] * rcp_sc;  // IEEE division (quant_per_thread.py:41) / fast path
-              if (!exact) {
-                const float z = fabsf(y) + 0.5f;
-                const float fr = z - floorf(z);
-                near |= (fr < 6.1035156e-5f) | (fr > 1.0f - 6.1035156e-5f);
-              }
-              y = y + (y >= 0.f ? 0.5f : -0.5f);
-              qv[e] = (int)y;
-            } else {
-              qv[e] = (int)rintf(f[e] * inv);  // cvt.rni (fused.cu:176-181)
-            }
-            qv[e] = min(max(qv[e], -128), 127) & 0xff;
+      for (int e = 0; e < 8; ++e) {
+        if (triton) {
+          float y = exact ? f[e] / sc : f[e] * rcp_sc;  // IEEE division (quant_per_thread.py:41) / fast path
+          if (!exact) {
+            const float z = fabsf(y) + 0.5f;
+            const float fr = z - floorf(z);
+            near |= (fr < 6.1035156e-5f) | (fr > 1.0f - 6.1035156e-5f);
           }
-          w[2 * c] = (uint32_t)qv[0] | ((uint32_t)qv[1] << 8) | ((uint32_t)qv[2] << 16) | ((uint32_t)qv[3] << 24);
-          w[2 * c + 1] = (uint32_t)qv[4] | ((uint32_t)qv[5] << 8) | ((uint32_t)qv[6] << 16) | ((uint32_t)qv[7] << 24);
+          y = y + (y >= 0.f ? 0.5f : -0.5f);
+          qv[e] = (int)y;
+        } else {
+          qv[e] = (int)rintf(f[e] * inv);  // cvt.rni (fused.cu:176-181)
         }
-        qf[ks][0] = (int)w[0]; qf[ks][1] = (int)w[1]; qf[ks][2] = (int)w[2]; qf[ks][3] = (int)w[3];
+        qv[e] = min(max(qv[e], -128), 127) & 0xff;
       }
-      return near || !(fabsf(rcp_sc) < 3.0e38f);
+      return near;
     };
-    if (__builtin_amdgcn_ballot_w64(quantize(false) && triton) != 0) (void)quantize(true);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint32_t w[4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float f[8];
+        unpack(raw[ks][c], f);
+        int qv[8];
+        const bool near = quant8(f, qv, false);
+        if (__builtin_amdgcn_ballot_w64(triton && (near || rcp_bad)) != 0) (void)quant8(f, qv, true);
+        w[2 * c] = (uint32_t)qv[0] | ((uint32_t)qv[1] << 8) | ((uint32_t)qv[2] << 16) | ((uint32_t)qv[3] << 24);
+        w[2 * c + 1] = (uint32_t)qv[4] | ((uint32_t)qv[5] << 8) | ((uint32_t)qv[6] << 16) | ((uint32_t)qv[7] << 24);
+      }
+      qf[ks][0] = (int)w[0]; qf[ks][1] = (int)w[1]; qf[ks][2] = (int)w[2]; qf[ks][3] = (int)w[3];
+    }
     qsc = sc * p.logit_mult;
   }
+  };
   const float* ksp = p.k_scale + b * p.ks_b + hk * p.ks_h;
 
   // ---- tile range
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
   // wave-uniform address: the scales of a tile come through the scalar cache (s_load_dwordx4, lgkmcnt), not through
   // vmcnt where they would queue behind the tile DMA.  The lane-half select is an fma with a zeroed partner
   // (x*q + z*0 is exactly x*q) instead of two v_mov + v_cndmask per scale: SGPR operands feed the VALU directly.
-  const float qsc_lo = hh ? 0.f : qsc, qsc_hi = hh ? qsc : 0.f;
+  float qsc_lo = 0.f, qsc_hi = 0.f;  // = hh ? (0, qsc) : (qsc, 0), set once the Q scale is known (prologue)
   auto load_kscales = [&](const int j) __attribute__((always_inline)) -> float4 {
     if constexpr (KTHREAD) return uniform_load4(ksp + j * p.ks_t);
     else return make_float4(uniform_load1(ksp + j * p.ks_t), 0.f, 0.f, 0.f);
@@ -656,9 +664,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
   static_assert(RING == 2 || (KC * T == 64 * KCH && VC * T == VROWS * VCH), "four-slot ring: every wave copies full shares");
   const int last_tile = ntiles - 1;
   if constexpr (RING == 2) {
+    if constexpr (V_REG) prepare_q();  // register-staged V: the tile's registers and the Q block's do not fit together
     dma_k(0, 0);
     load_v(0, 0);
     if (ntiles > 1) dma_k(1, 1);
+    if constexpr (!V_REG) prepare_q();
     finish_tile(0, true);
   } else {
     // K(0..3) and V(0..2), clamped to the last tile so that every wave issues the same number of copies whatever the
@@ -671,8 +681,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
     dma_k(min(2, last_tile), 2);
     load_v(min(2, last_tile), 2);
     dma_k(min(3, last_tile), 3);
+    prepare_q();
     dma_wait_keep<2 * NDMA>();
   }
+  qsc_lo = hh ? 0.f : qsc;
+  qsc_hi = hh ? qsc : 0.f;
   __syncthreads();
 
   if constexpr (HAS_MASK) {
