@@ -264,6 +264,22 @@ def main():
             port, sdpa = cpu_baseline(D, causal)
             out["cpu_baseline"] = port
             out["cpu_sdpa"] = sdpa
+    if use_dist and world > 1 and wl == "ring" and args.sp == "ring":
+        # context for the driver's scaling table (N = 1 runs C3, a different workload): the SAME problem on ONE GPU through the
+        # single-GPU operator, a few launches on rank 0 after the timed region; the other ranks wait at the barrier
+        if rank == 0:
+            try:
+                qa, ka, va = (torch.randn(B, H, N, D, dtype=torch.float16, device=dev) for _ in range(3))
+                entry1 = sa.sageattn_qk_int8_pv_fp16_cuda if variant == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+                one_ms = time_events(lambda: entry1(qa, ka, va, is_causal=causal, qk_quant_gran=args.gran), 3, 1)
+                one_tf = total_flops / (one_ms * 1e-3) / 1e12
+                out["one_gpu_same_problem"] = {"ms": round(one_ms, 4), "tflops": round(one_tf, 2),
+                                               "speedup": round(value / one_tf, 3), "of_ideal": round(value / one_tf / world, 3)}
+                del qa, ka, va
+            except Exception as e:  # context only
+                out["one_gpu_same_problem"] = {"error": repr(e)[:200]}
+        torch.cuda.synchronize()
+        dist.barrier()
     if use_dist:
         dist.destroy_process_group()
     if saved_stdout is not None:
