@@ -183,18 +183,17 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (triton) {
-          float y = exact ? f[e] / sc : f[e] * rcp_sc;  // IEEE division (quant_per_thread.py:41) / fast path
-          if (!exact) {
-            const float z = fabsf(y) + 0.5f;
-            const float fr = z - floorf(z);
-            near |= (fr < 6.1035156e-5f) | (fr > 1.0f - 6.1035156e-5f);
+          if (exact) {
+            float y = f[e] / sc;  // IEEE division (quant_per_thread.py:41)
+            y = y + (y >= 0.f ? 0.5f : -0.5f);
+            qv[e] = (int)y;
+          } else {
+            qv[e] = round_half_away_fast(f[e] * rcp_sc, near);
           }
-          y = y + (y >= 0.f ? 0.5f : -0.5f);
-          qv[e] = (int)y;
         } else {
           qv[e] = (int)rintf(f[e] * inv);  // cvt.rni (fused.cu:176-181)
         }
-        qv[e] = min(max(qv[e], -128), 127) & 0xff;
+        qv[e] = min(max(qv[e], -128), 127);
       }
       return near;
     };
@@ -208,8 +207,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
         int qv[8];
         const bool near = quant8(f, qv, false);
         if (__builtin_amdgcn_ballot_w64(triton && (near || rcp_bad)) != 0) (void)quant8(f, qv, true);
-        w[2 * c] = (uint32_t)qv[0] | ((uint32_t)qv[1] << 8) | ((uint32_t)qv[2] << 16) | ((uint32_t)qv[3] << 24);
-        w[2 * c + 1] = (uint32_t)qv[4] | ((uint32_t)qv[5] << 8) | ((uint32_t)qv[6] << 16) | ((uint32_t)qv[7] << 24);
+        w[2 * c] = pack_i8x4(qv[0], qv[1], qv[2], qv[3]);
+        w[2 * c + 1] = pack_i8x4(qv[4], qv[5], qv[6], qv[7]);
       }
       qf[ks][0] = (int)w[0]; qf[ks][1] = (int)w[1]; qf[ks][2] = (int)w[2]; qf[ks][3] = (int)w[3];
     }

@@ -55,6 +55,29 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
   }
 }
 
+// Four int32 already clamped to [-128, 127] -> their low bytes in one dword: 3 v_perm_b32 instead of 4 masks + 3 shift-ors.
+// v_perm_b32 D, S0, S1, sel: selector bytes 0-3 pick bytes of S1, 4-7 bytes of S0, 0x0c a zero byte.
+__device__ __forceinline__ uint32_t pack_i8x4(int a, int b, int c, int d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u);
+  const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x0c0c0400u);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+#else
+  return ((uint32_t)a & 0xffu) | (((uint32_t)b & 0xffu) << 8) | (((uint32_t)c & 0xffu) << 16) | (((uint32_t)d & 0xffu) << 24);
+#endif
+}
+
+// Half-away-from-zero rounding of y = x / scale the cheap way (the Triton quantizers, quant_per_block.py:42-44): q = rint(y)
+// agrees with trunc(y + 0.5 sign y) unless y sits on a rounding boundary; `near` reports |y - rint(y)| > 0.5 - 2^-14, the
+// band in which (a) the two roundings or (b) the reciprocal product and the IEEE division the reference uses could
+// differ (|x*r - x/sc| <= 2.3e-5 for |y| <= 127, plus 7.6e-6 from the reference's rounded y + 0.5): the caller then redoes
+// the chunk with the exact division.  4 VALU per element (v_rndne, v_sub, v_cmp, v_cvt) against 7 for fract-based forms.
+__device__ __forceinline__ int round_half_away_fast(float y, bool& near) {
+  const float rn = rintf(y);
+  near |= fabsf(y - rn) > 0.5f - 6.1035156e-5f;
+  return (int)rn;
+}
+
 // hipGetLastError() is sticky per host thread: every entry point clears it before its first launch (launch_begin), so
 // that launch_status() reports THIS call's launches and not a stale error of an earlier, unrelated runtime call.
 __host__ inline void launch_begin() { (void)hipGetLastError(); }

@@ -238,13 +238,7 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
       const float r = 1.0f / sc;
       bool near = false;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float ya = xf[i][j] * r;
-        // fractional part of |ya| + 0.5 within 2^-14 of 0 or 1  <=>  |fract - 0.5| > 0.5 - 2^-14  (v_fract, v_sub, v_cmp)
-        const float f = __builtin_amdgcn_fractf(fabsf(ya) + 0.5f);
-        near |= fabsf(f - 0.5f) > 0.5f - 6.1035156e-5f;
-        q[j] = (int)(ya + __builtin_copysignf(0.5f, ya));
-      }
+      for (int j = 0; j < 8; ++j) q[j] = round_half_away_fast(xf[i][j] * r, near);
       if (__builtin_amdgcn_ballot_w64(near || !(fabsf(r) < 3.0e38f)) != 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -258,12 +252,9 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
 #pragma unroll
       for (int j = 0; j < 8; ++j) q[j] = (int)rintf(xf[i][j] * inv);  // cvt.rni (fused.cu:176-181)
     }
-    uint32_t w0 = 0, w1 = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      w0 |= (uint32_t)(min(max(q[j], -128), 127) & 0xff) << (8 * j);
-      w1 |= (uint32_t)(min(max(q[4 + j], -128), 127) & 0xff) << (8 * j);
-    }
+    for (int j = 0; j < 8; ++j) q[j] = min(max(q[j], -128), 127);
+    const uint32_t w0 = pack_i8x4(q[0], q[1], q[2], q[3]), w1 = pack_i8x4(q[4], q[5], q[6], q[7]);
     if (row < N_) *reinterpret_cast<uint2*>(obase + (int64_t)lr * p.osn) = make_uint2(w0, w1);
   }
 }
