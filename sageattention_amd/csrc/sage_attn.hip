@@ -29,7 +29,10 @@ constexpr int attn_ring_slots(int D, int nwaves, bool pv_fp8) { return (pv_fp8 &
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
 template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8, bool HAS_MASK>
-__global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 3) ? 3 : SAGE_MINWAVES) void attn_i8_kernel(const AttnParams p) {
+// (head_dim 64 FP8 PV in its dispatched 4-wave geometry is told to stay within 168 registers = three waves per SIMD: it fits
+//  without scratch, but left alone hipcc settles a few registers above the line)
+__global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && NWAVES == 4 && SAGE_MINWAVES < 3) ? 3 : SAGE_MINWAVES)
+void attn_i8_kernel(const AttnParams p) {
   static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
   static_assert(!HAS_MASK || (!CAUSAL && !PV_FP8 && !V_BF16), "attn_mask: non-causal fp16-PV operator, fp16 V");
   constexpr int T = NWAVES * 64;
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && SAGE_MINWAVES < 
     if (has_next) {
       tile_scales(j + 1, nsc0, nsc1);
       qk((j + 1) % RING, s_nxt);
-      mask_limit(j + 1, s_nxt);
+      if (j + 1 >= n_plain) mask_limit(j + 1, s_nxt);  // a plain last tile (N % 64 == 0, no diagonal) needs none
     }
     softmax_pv(j, j % RING, s_cur, sc0, sc1, std::true_type{});
     if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
