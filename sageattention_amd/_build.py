@@ -39,6 +39,21 @@ def _check_no_scratch(src, compiler_output):
             raise RuntimeError(f"{src}: kernel {name} uses {m.group(1)} bytes/lane of scratch (register spill)")
 
 
+def _check_occupancy(src, compiler_output):
+    """The head_dim-64 kernels in their dispatched geometry (4 waves, no attn_mask) are tuned for THREE waves per SIMD
+    (<= 168 VGPRs); hipcc's allocation sits within a few registers of that line and an innocent-looking source change can
+    push a variant over it (-5 ... -10 % on the head_dim-64 shapes, silently).  Fail the build instead."""
+    import re
+    name = None
+    for line in compiler_output.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r" VGPRs: (\d+)", line)
+        if m and name and re.search(r"attn_i8_kernelILi64ELi4E(Lb[01]E){4}Lb0EEE", name) and int(m.group(1)) > 168:
+            raise RuntimeError(f"{src}: kernel {name} uses {m.group(1)} VGPRs (> 168: two waves per SIMD instead of three)")
+
+
 def _check_m0_private(obj):
     """lds_dma16 (sage_attn_common.h) sets M0 and declares it clobbered instead of saving and restoring it; clang does not
     honour clobbers of reserved registers, so this is only sound while nothing else in the device code touches M0.
@@ -114,6 +129,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         try:
             _check_no_scratch(src, out)
+            _check_occupancy(src, out)
             if src == "sage_attn.hip":
                 _check_m0_private(os.path.join(CSRC, "sage_attn.o"))
         except RuntimeError:
