@@ -731,27 +731,54 @@ void attn_i8_kernel(const AttnParams p) {
 
   // fast loop, unrolled by two so that S(j) / S(j+1) swap roles without register copies
   float4 kk_nxt = load_kscales(min(1, ntiles - 1));
-  auto fast_iter = [&](auto par_tag, const int j, v16i (&sa)[2], v16i (&sb)[2], float& a0, float& a1, float& b0,
+  int k_slot = 0, v_slot = 0;  // slots the LDS read pointers point at (moved by the run-time-slot tiles only)
+  // NEXT (second tag): what follows tile j for this wave.
+  //   0  a plain tile: the fast loops.  Ring slots are compile-time (R = j % RING), every LDS offset an immediate.
+  //   1  a tile that may need masking (sequence end, causal diagonal), 2  nothing (the wave's last tile): the remaining
+  //      tiles of a wave run through the SAME hand-placed stream with run-time ring slots (a few address adds) -- the
+  //      compiler-scheduled body they used before was 1.6x slower per tile, 5-7 % of a short causal sequence.
+  auto fast_iter = [&](auto par_tag, auto next_tag, const int j, v16i (&sa)[2], v16i (&sb)[2], float& a0, float& a1, float& b0,
                        float& b1) __attribute__((always_inline)) {
     constexpr int R = decltype(par_tag)::value;  // j % RING, static so every LDS offset is an immediate
-    constexpr int PAR = R & 1;                    // which of the two S register sets is consumed
-    constexpr int K_RD = (R + 1) % RING, V_RD = R, K_WR = R, V_WR = (R + RING - 1) % RING;  // slots of K(j+1), V(j), K(j+RING), V(j+RING-1)
-    (void)PAR;
+    constexpr int NEXT = decltype(next_tag)::value;
+    constexpr bool DYN = NEXT != 0;
+    // slots of K(j+1), V(j), K(j+RING), V(j+RING-1)
+    const int K_RD = DYN ? (j + 1) % RING : (R + 1) % RING, V_RD = DYN ? j % RING : R, K_WR = V_RD,
+              V_WR = DYN ? (j + RING - 1) % RING : (R + RING - 1) % RING;
     // The first K fragment of S(j+1) is read BEFORE the tile copies are issued: the first S MFMA needs it at once, and the
     // copies are inline asm with a memory clobber, so the compiler cannot hoist the read across them itself (+0.2..0.8 %).
     // scales of tile j+1 were fetched during the previous iteration; those of tile j+2 are fetched first thing here: the
     // scalar load shares lgkmcnt with the LDS reads, so it must be in flight long before the first wait on a K fragment
     // (left to hipcc it is issued right in front of that wait and every iteration pays a scalar-cache round trip)
-    scales_from(kk_nxt, b0, b1);
-    kk_nxt = load_kscales(min(j + 2, ntiles - 1));
+    if constexpr (DYN) {
+      // run-time slots without extra address registers: the read pointers themselves move to the slots of this tile (the
+      // fast loops, which need them at the region base, are over) and every offset below stays an immediate
+      if constexpr (NEXT != 2) {
+        const int dk = (K_RD - k_slot) * KBYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_rd[ks] += dk;
+        k_slot = K_RD;
+      }
+      const int dv = (V_RD - v_slot) * VBYTES;
+      if constexpr (PV_FP8) { v_rd8[0] += dv; v_rd8[1] += dv; }
+      else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) v_rd[dt] += dv;
+      }
+      v_slot = V_RD;
+    }
     v4i kf_early = qf[0];
-    if constexpr (!abl::kNoLdsK) kf_early = *reinterpret_cast<const v4i*>(k_rd[0] + K_RD * KBYTES);
+    if constexpr (NEXT != 2) {
+      scales_from(kk_nxt, b0, b1);
+      kk_nxt = load_kscales(min(j + 2, ntiles - 1));
+      if constexpr (!abl::kNoLdsK) kf_early = *reinterpret_cast<const v4i*>(k_rd[0] + (DYN ? 0 : K_RD * KBYTES));
+    }
     __builtin_amdgcn_sched_barrier(0);
     maybe_rescale(mx_cur);
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
         if (j + 2 < ntiles) dma_k(j + 2, K_WR);
-        load_v(j + 1, V_WR);
+        if (!DYN || j + 1 < ntiles) load_v(j + 1, V_WR);
       } else {
         dma_k(min(j + RING, last_tile), K_WR);
         load_v(min(j + RING - 1, last_tile), V_WR);
@@ -759,9 +786,10 @@ void attn_i8_kernel(const AttnParams p) {
     }
     constexpr int HAND_PLACED = PV_FP8 ? abl::kHandPlacedF8 : abl::kHandPlacedF16;
     if constexpr (HAND_PLACED == 0) {
-      qk(K_RD, sb);
-      softmax_pv(j, V_RD, sa, a0, a1, std::false_type{});
-      mx_cur = row_max(sb, b0, b1);
+      if constexpr (NEXT != 2) qk(DYN ? 0 : K_RD, sb);
+      if constexpr (NEXT == 1) { if (j + 1 >= n_plain) mask_limit(j + 1, sb); }
+      softmax_pv(j, DYN ? 0 : V_RD, sa, a0, a1, std::false_type{});
+      if constexpr (NEXT != 2) mx_cur = row_max(sb, b0, b1);
     } else if constexpr (HAND_PLACED == 2) {
       // Hand-placed stream, FP8 PV.  The K = 64 MFMA consumes the P of the whole tile, so all of P(j) precedes the P.V
       // MFMAs; left alone hipcc emits ~110 softmax VALU instructions with the matrix pipe idle and then the 12 MFMAs in
@@ -770,7 +798,7 @@ void attn_i8_kernel(const AttnParams p) {
       // words are computed, and the four P.V MFMAs run beside the row max of S(j+1).
       constexpr int NS = 2 * KS;       // S MFMAs per tile
       constexpr int WPS = 8 / NS;      // P words per S MFMA (1 at head_dim 128, 2 at 64)
-      constexpr int kb = K_RD * KBYTES, vb = V_RD * VBYTES;  // slot offsets inside the K / V regions
+      const int kb = DYN ? 0 : K_RD * KBYTES, vb = DYN ? 0 : V_RD * VBYTES;  // slot offsets (DYN: the pointers were moved)
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
         return *reinterpret_cast<const v4i*>(k_rd[i % KS] + (kb + (i / KS) * 32 * D));
@@ -806,7 +834,7 @@ void attn_i8_kernel(const AttnParams p) {
       int si = 0;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
-        if (w % WPS == 0) {
+        if (NEXT != 2 && w % WPS == 0) {
           s_step(si, kf);
           if (si + 1 < NS) kf = k_frag(si + 1);
           ++si;
@@ -820,24 +848,29 @@ void attn_i8_kernel(const AttnParams p) {
       p_sum();
       l_run += psum;
       // P.V beside the row max of S(j+1)
+      if constexpr (NEXT == 1) { if (j + 1 >= n_plain) mask_limit(j + 1, sb); }
       int mxa = sb[0][0], mxb = sb[0][2];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         if (dt + 2 < DT) vf[dt + 2] = v_frag8(dt + 2);
         acc_o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[dt], pb, acc_o[dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        if constexpr (NEXT != 2) {
 #pragma unroll
-        for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
-          const int mt = idx >> 4, e = idx & 15;
-          if (e & 2) mxb = max(mxb, sb[mt][e]); else mxa = max(mxa, sb[mt][e]);
+          for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
+            const int mt = idx >> 4, e = idx & 15;
+            if (e & 2) mxb = max(mxb, sb[mt][e]); else mxa = max(mxa, sb[mt][e]);
+          }
+          asm volatile("" : "+v"(mxa), "+v"(mxb));
         }
-        asm volatile("" : "+v"(mxa), "+v"(mxb));
         SAGE_FENCE();
       }
 #undef SAGE_FENCE
-      float mx;
-      if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * b0, (__int_as_float(mxb) - kBiasF) * b1);
-      else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
-      mx_cur = swap_max(mx);
+      if constexpr (NEXT != 2) {
+        float mx;
+        if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * b0, (__int_as_float(mxb) - kBiasF) * b1);
+        else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
+        mx_cur = swap_max(mx);
+      }
     } else {
       // Hand-placed instruction stream (fp16 PV).  The wave issues in order and an MFMA that finds the matrix pipe
       // busy blocks the VALU instructions behind it, so what counts is what sits BETWEEN consecutive MFMAs: about
@@ -848,7 +881,7 @@ void attn_i8_kernel(const AttnParams p) {
       // the row max of S(j+1) runs beside the last quarter's MFMAs.  sched_barrier(0) pins each group.
       constexpr int NS = 2 * KS, SPR = NS / 4;  // S MFMAs per tile / per region
       constexpr int PPG = 4 / DT;               // P pairs computed beside one P.V MFMA
-      constexpr int kb = K_RD * KBYTES, vb = V_RD * VBYTES;  // slot offsets inside the K / V regions
+      const int kb = DYN ? 0 : K_RD * KBYTES, vb = DYN ? 0 : V_RD * VBYTES;  // slot offsets (DYN: the pointers were moved)
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
         if constexpr (abl::kNoLdsK) return qf[i % KS];
@@ -888,8 +921,10 @@ void attn_i8_kernel(const AttnParams p) {
       // region 0: P(quarter 0) beside the first S MFMAs; V^T fragments of quarter 0
 #pragma unroll
       for (int g = 0; g < SPR; ++g) {
-        s_step(g, kf);
-        kf = k_frag(g + 1);
+        if constexpr (NEXT != 2) {
+          s_step(g, kf);
+          kf = k_frag(g + 1);
+        }
 #pragma unroll
         for (int dt = g * (DT / SPR); dt < (g + 1) * (DT / SPR); ++dt) vf[dt] = v_frag(0, dt);
 #pragma unroll
@@ -913,7 +948,7 @@ void attn_i8_kernel(const AttnParams p) {
             p_pair(q, pr, pn);
           }
           SAGE_FENCE();
-          if ((dt + 1) % (DT / SPR) == 0) {
+          if (NEXT != 2 && (dt + 1) % (DT / SPR) == 0) {
             s_step(si, kf);
             if (si + 1 < NS) kf = k_frag(si + 1);
             ++si;
@@ -926,27 +961,34 @@ void attn_i8_kernel(const AttnParams p) {
       }
       // tail: P.V of quarter 3 beside the row max of S(j+1)
       p_sum(3);
+      if constexpr (NEXT == 1) { if (j + 1 >= n_plain) mask_limit(j + 1, sb); }
       int mxa = sb[0][0], mxb = sb[0][2];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt], pf, acc_o[dt], 0, 0, 0);
+        if constexpr (NEXT != 2) {
 #pragma unroll
-        for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
-          const int mt = idx >> 4, e = idx & 15;
-          if (e & 2) mxb = max(mxb, sb[mt][e]); else mxa = max(mxa, sb[mt][e]);
+          for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
+            const int mt = idx >> 4, e = idx & 15;
+            if (e & 2) mxb = max(mxb, sb[mt][e]); else mxa = max(mxa, sb[mt][e]);
+          }
+          asm volatile("" : "+v"(mxa), "+v"(mxb));  // keeps this part of the max chain here (integer max re-associates)
         }
-        asm volatile("" : "+v"(mxa), "+v"(mxb));  // keeps this part of the max chain here (integer max re-associates)
         SAGE_FENCE();
       }
 #undef SAGE_FENCE
-      float mx;
-      if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * b0, (__int_as_float(mxb) - kBiasF) * b1);
-      else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
-      mx_cur = swap_max(mx);
+      if constexpr (NEXT != 2) {
+        float mx;
+        if constexpr (KTHREAD) mx = max_raw((__int_as_float(mxa) - kBiasF) * b0, (__int_as_float(mxb) - kBiasF) * b1);
+        else mx = (__int_as_float(max(mxa, mxb)) - kBiasF) * b0;
+        mx_cur = swap_max(mx);
+      }
     }
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
-        finish_tile(V_WR, true);
+        finish_tile(V_WR, !DYN || j + 1 < ntiles);
+      } else if constexpr (DYN) {
+        dma_wait_all();  // the last tiles of a wave drain every copy (the counts of the four-slot ring stay constant)
       } else {
         dma_wait_keep<2 * NDMA>();  // K(j+2), V(j+1) and everything older have landed; the last two iterations' copies fly on
       }
@@ -955,24 +997,25 @@ void attn_i8_kernel(const AttnParams p) {
   };
   float nsc0 = 0.f, nsc1 = 0.f;
   int j = 0;
+  constexpr std::integral_constant<int, 0> kPlainNext{};
   if constexpr (RING == 4) {
     // four-slot ring: the slot pattern repeats every four tiles
     for (; j + 3 < n_fast; j += 4) {
-      fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
-      fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
-      fast_iter(std::integral_constant<int, 2>{}, j + 2, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
-      fast_iter(std::integral_constant<int, 3>{}, j + 3, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+      fast_iter(std::integral_constant<int, 0>{}, kPlainNext, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      fast_iter(std::integral_constant<int, 1>{}, kPlainNext, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+      fast_iter(std::integral_constant<int, 2>{}, kPlainNext, j + 2, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      fast_iter(std::integral_constant<int, 3>{}, kPlainNext, j + 3, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
     }
     // up to three fast tiles left (j % 4 == 0 here); after an odd number the live scores sit in the other register set
     bool odd = false;
     if (j < n_fast) {
-      fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      fast_iter(std::integral_constant<int, 0>{}, kPlainNext, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
       ++j; odd = true;
       if (j < n_fast) {
-        fast_iter(std::integral_constant<int, 1>{}, j, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+        fast_iter(std::integral_constant<int, 1>{}, kPlainNext, j, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
         ++j; odd = false;
         if (j < n_fast) {
-          fast_iter(std::integral_constant<int, 2>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+          fast_iter(std::integral_constant<int, 2>{}, kPlainNext, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
           ++j; odd = true;
         }
       }
@@ -983,14 +1026,14 @@ void attn_i8_kernel(const AttnParams p) {
     }
   } else {
   for (; j + 1 < n_fast; j += 2) {
-    fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
-    fast_iter(std::integral_constant<int, 1>{}, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
+    fast_iter(std::integral_constant<int, 0>{}, kPlainNext, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+    fast_iter(std::integral_constant<int, 1>{}, kPlainNext, j + 1, s_nxt, s_cur, nsc0, nsc1, sc0, sc1);
   }
   // an odd fast tile left (j is even here): one more fast iteration instead of a generic one (+11 % at C2, where the
   // generic body otherwise takes 2 of 32 tiles).
   if constexpr (!abl::kNoOddFast) {
     if (j < n_fast) {
-      fast_iter(std::integral_constant<int, 0>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      fast_iter(std::integral_constant<int, 0>{}, kPlainNext, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
       s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
       sc0 = nsc0; sc1 = nsc1;
       ++j;
@@ -1014,21 +1057,39 @@ void attn_i8_kernel(const AttnParams p) {
       load_v(min(jj + RING - 1, last_tile), (jj + RING - 1) % RING);
     }
   };
-  for (; j < wave_tiles; ++j) {
-    maybe_rescale(mx_cur);
-    stage_generic(j);
-    const bool has_next = j + 1 < wave_tiles;
-    if (has_next) {
-      tile_scales(j + 1, nsc0, nsc1);
-      qk((j + 1) % RING, s_nxt);
-      if (j + 1 >= n_plain) mask_limit(j + 1, s_nxt);  // a plain last tile (N % 64 == 0, no diagonal) needs none
+  // The wave's remaining tiles (a successor that may need masking, then its last one).
+  //  * FP16 PV (not the register-staged bf16 V of head_dim 128) and FP8 PV at head_dim 64: the same hand-placed stream with
+  //    run-time slots (fast_iter, NEXT = 1 / 2): C2 +0.8 %, C2-fp8 +1.6 %, (8,32,2048,128) causal +3.5 %.
+  //  * FP8 PV at head_dim 128 and register-staged V: the compiler-scheduled body.  With the stream variants instantiated
+  //    their MAIN loop came out 0.3-1 % slower (different register assignment), more than the tail tiles return.
+  constexpr bool STREAM_TAIL = !(V_REG || (PV_FP8 && D == 128));
+  if constexpr (STREAM_TAIL) {
+    for (; j + 1 < wave_tiles; ++j) {
+      fast_iter(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
+      sc0 = nsc0; sc1 = nsc1;
     }
-    softmax_pv(j, j % RING, s_cur, sc0, sc1, std::true_type{});
-    if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
-    finish_tile((j + 1) & 1, j + 1 < ntiles);
-    __syncthreads();
-    s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
-    sc0 = nsc0; sc1 = nsc1;
+    if (j < wave_tiles) {
+      fast_iter(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);
+      ++j;
+    }
+  } else {
+    for (; j < wave_tiles; ++j) {
+      maybe_rescale(mx_cur);
+      stage_generic(j);
+      const bool has_next = j + 1 < wave_tiles;
+      if (has_next) {
+        tile_scales(j + 1, nsc0, nsc1);
+        qk((j + 1) % RING, s_nxt);
+        if (j + 1 >= n_plain) mask_limit(j + 1, s_nxt);  // a plain last tile (N % 64 == 0, no diagonal) needs none
+      }
+      softmax_pv(j, j % RING, s_cur, sc0, sc1, std::true_type{});
+      if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
+      finish_tile((j + 1) & 1, j + 1 < ntiles);
+      __syncthreads();
+      s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
+      sc0 = nsc0; sc1 = nsc1;
+    }
   }
   for (; j < ntiles; ++j) {
     stage_generic(j);
