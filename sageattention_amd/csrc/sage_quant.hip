@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void kv_partial_kernel(const uint16_t* __restr
 }
 
 template <int D, bool BF16>
-__global__ __launch_bounds__(256) void kv_quant_kernel(const QuantParams p, const VPrepParams q, const int nblk_k) {
+__global__ __launch_bounds__(256, D == 64 ? 8 : 7) void kv_quant_kernel(const QuantParams p, const VPrepParams q, const int nblk_k) {
   using G = VQuantGeom<D>;
   __shared__ unsigned int gmax[64];
   __shared__ __attribute__((aligned(16))) float exch[16][D];  // chunk partials of this head: K sums or V max|v|
