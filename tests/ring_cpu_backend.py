@@ -109,7 +109,7 @@ class OracleGatherBackend:
             k8, ks = O.quant_int8_grouped(k, gid, ng, mean=self.km4, rounding="cuda")
         parts = [k8.contiguous(), ks.contiguous()]
         if self.pv == "fp8":
-            y = v.float().transpose(2, 3) * (O.FP8_E4M3_MAX / self.amax).unsqueeze(-1)   # quant.py:318-321 with the GLOBAL amax
+            y = v.float().transpose(2, 3) * O._ieee_div(O.FP8_E4M3_MAX, self.amax).unsqueeze(-1)   # quant.py:318-321 with the GLOBAL amax
             parts.append(y.clamp(-O.FP8_E4M3_MAX, O.FP8_E4M3_MAX).to(torch.float8_e4m3fn).contiguous())
         else:
             parts.append(v.contiguous())
