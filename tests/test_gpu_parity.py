@@ -137,10 +137,11 @@ def test_end_to_end_vs_oracle(sa, golden, gran, nwaves):
 @pytest.mark.parametrize("smooth_v", [False, True])
 def test_v_fp8_quantizer_vs_oracle(sa, golden, smooth_v):
     """FP8 V quantizer (CUDA/HIP-only in the reference: parity unpinned by it).  Against the oracle's restatement of
-    fused.cu:316-427 with OCP e4m3: scales bit-exact without smoothing (max/min are order independent); e4m3 bytes:
-    v_cvt_pk_fp8_f32 resolves inputs within ~1e-7 (relative) of a rounding tie AS a tie (measured: 168.000015 -> 160,
-    13.499999 -> 14), and with smoothing the channel mean is a differently ordered fp32 sum, so <= 0.1 % of the bytes
-    may differ, each by exactly one code."""
+    fused.cu:316-427 with OCP e4m3.  Without smoothing everything is bit-exact: scales (max/min are order independent) and
+    every e4m3 byte, exact rounding ties included (bf16 inputs produce them by the hundred; round 1 saw ~0.1 % of the
+    bytes differ there and blamed v_cvt_pk_fp8_f32 -- the cause was the ORACLE's reciprocal, python's `scalar / tensor` being
+    reciprocal * scalar in torch, 1 ulp off the single division the C source means; oracle._ieee_div).  With smoothing the
+    channel mean is a differently ordered fp32 sum, so <= 0.5 % of the bytes may differ, each by exactly one code."""
     from oracle import sage_oracle as O
     g, m = golden, golden.meta
     v8, vs, vm = sa.quant.per_channel_fp8(g.v.cuda(), tensor_layout=m["layout"], smooth_v=smooth_v)
@@ -161,8 +162,37 @@ def test_v_fp8_quantizer_vs_oracle(sa, golden, smooth_v):
     valid = (idx < m["N"])
     assert (got[..., ~valid] == 0).all()
     got, want = got[..., valid], want[..., valid]
-    assert (got != want).float().mean() < 5e-3  # bf16 inputs land on near-ties more often (8-bit mantissas)
+    if not smooth_v:
+        assert torch.equal(got, want), int((got != want).sum())
+    assert (got != want).float().mean() < 5e-3
     assert (got.int() - want.int()).abs().max() <= 1
+
+
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+def test_v_fp8_quantizer_bit_exact_on_rounding_ties(sa, layout):
+    """bf16 V (8-bit mantissas) times 448/amax lands on EXACT e4m3 rounding ties hundreds of times per tensor: every byte must
+    equal the oracle's (round-to-nearest-even of one correctly rounded product with one correctly rounded quotient)."""
+    from oracle import sage_oracle as O
+    g = torch.Generator().manual_seed(7110)
+    B, H, N, D = 2, 3, 415, 128
+    shape = (B, H, N, D) if layout == "HND" else (B, N, H, D)
+    v = torch.randn(shape, generator=g).to(torch.bfloat16)
+    v8, vs, _ = sa.quant.per_channel_fp8(v.cuda(), tensor_layout=layout, smooth_v=False)
+    r8, rs, _ = O.per_channel_fp8(v, tensor_layout=layout, smooth_v=False)
+    perm = sa.quant.fp8_token_order()
+    nblk = v8.shape[-1] // 64
+    idx = (torch.arange(nblk).view(-1, 1) * 64 + perm.view(1, -1)).reshape(-1)
+    valid = idx < N
+    got = v8.cpu().view(torch.uint8)[..., valid]
+    want = r8.view(torch.uint8)[..., idx][..., valid]
+    assert torch.equal(vs.cpu(), rs)
+    assert torch.equal(got, want), int((got != want).sum())
+    # the data really exercises ties: products exactly half way between two e4m3 codes (spacing 2^(floor(log2|x|) - 3))
+    vh = v.float() if layout == "HND" else v.float().transpose(1, 2)
+    x = (vh * O._ieee_div(448.0, vh.abs().amax(2, keepdim=True))).abs()
+    x = x[x >= 2.0 ** -6]
+    u = x / torch.exp2(torch.floor(torch.log2(x)) - 3)
+    assert int(((u - torch.floor(u)) == 0.5).sum()) > 100
 
 
 @pytest.mark.parametrize("gran", ["per_warp", "per_thread"])
