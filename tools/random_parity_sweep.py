@@ -5,6 +5,7 @@ import sageattention_amd as sa
 from oracle import sage_oracle as O
 from sageattention_amd import _lib as L
 seed0 = int(sys.argv[1]); count = int(sys.argv[2])
+maxlen = int(sys.argv[3]) if len(sys.argv) > 3 else 900
 rng = random.Random(seed0)
 t0 = time.time(); worst = {}
 for it in range(count):
@@ -13,8 +14,8 @@ for it in range(count):
     Hk = rng.choice([1, 2, 3]); Hq = Hk * rng.choice([1, 2, 4])
     D = rng.choice([64, 128, 64, 128, 40, 96])
     causal = rng.random() < 0.5
-    M = rng.randint(1, 700)
-    N = M if (causal and rng.random() < 0.7) else rng.randint(1, 900)
+    M = rng.randint(1, maxlen)
+    N = M if (causal and rng.random() < 0.7) else rng.randint(1, maxlen)
     B = rng.choice([1, 2])
     pv = rng.choice(["fp16", "fp8"])
     gran = rng.choice(["per_warp", "per_thread"])
