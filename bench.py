@@ -264,7 +264,7 @@ def main():
             port, sdpa = cpu_baseline(D, causal)
             out["cpu_baseline"] = port
             out["cpu_sdpa"] = sdpa
-    if use_dist and world > 1 and wl == "ring" and args.sp == "ring":
+    if use_dist and world > 1 and wl == "ring":
         # context for the driver's scaling table (N = 1 runs C3, a different workload): the SAME problem on ONE GPU through the
         # single-GPU operator, a few launches on rank 0 after the timed region; the other ranks wait at the barrier
         if rank == 0:
