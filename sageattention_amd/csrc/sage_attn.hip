@@ -225,7 +225,7 @@ void attn_i8_kernel(const AttnParams p) {
   const int ntiles = (kv_end + 63) >> 6;
   const int wave_tiles = CAUSAL ? min(ntiles, ((q0 + 31) >> 6) + 1) : ntiles;
 
-  // ---- staging (global -> regs -> LDS).  Raw buffer loads: the descriptor holds the (b, h_kv) slice, the
+  // ---- staging (global -> LDS by LDS-DMA; bf16 V at head_dim 128 through registers).  Buffer addressing: the descriptor holds the (b, h_kv) slice, the
   //      per-thread byte offset is constant for the whole kernel and the tile advance is a scalar offset, so a
   //      tile costs no address VALU; rows >= N fall outside num_records and read as ZERO (V rows beyond the
   //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
@@ -650,7 +650,7 @@ void attn_i8_kernel(const AttnParams p) {
   //      computes S(j+1) = K(j+1).Q^T (MFMA) while it exponentiates S(j) (VALU) and accumulates P(j).V(j);
   //      K(j+2) and V(j+1) are copied global -> LDS during the iteration (LDS-DMA, drained in front of the barrier).
   //   [0, n_fast)           tiles j and j+1 both unmasked: branch-free body
-  //   [n_fast, wave_tiles)  generic body (masks, last tile)
+  //   [n_fast, wave_tiles)  the wave's last tiles (a successor that may need masking; the final tile): run-time ring slots
   //   [wave_tiles, ntiles)  causal only: this wave is done but still stages tiles for its workgroup
   // Every wave executes the same number of barriers.
   int n_plain = wave_tiles;
@@ -1046,7 +1046,7 @@ void attn_i8_kernel(const AttnParams p) {
     row_l = q0 + (ln & 31);
     hh_l = ln >> 5;
   }
-  // generic body (masked / last tiles) and, for causal waves that are done early, staging-only iterations: runtime slots,
+  // staging with run-time slots: the compiler-scheduled tail body below and, for causal waves that are done early, staging-only iterations;
   // every copy drained (vmcnt(0)) -- the four-slot ring keeps its copy COUNT per iteration constant here as well
   auto stage_generic = [&](const int jj) __attribute__((always_inline)) {
     if constexpr (RING == 2) {
