@@ -4,8 +4,9 @@
 // csrc/qattn/qk_int_sv_f8_cuda_sm89.cuh:44-713 (semantics), designed for wave64 + MFMA:
 //
 //  * one wave owns 32 query rows; a workgroup of NWAVES waves owns NWAVES*32 rows and shares the
-//    K/V tiles (64 keys) through a double-buffered LDS ring, register-staged (global -> VGPR early,
-//    VGPR -> LDS after the PV MFMAs) so HBM/L2 latency hides under the MFMA phases.
+//    K/V tiles (64 keys) through an LDS ring (two slots, four for FP8 PV) filled by LDS-DMA (buffer_load ... lds): a
+//    copy is issued one to four tiles ahead and drained by a counted s_waitcnt in front of the barrier that publishes it,
+//    so HBM/L2 latency hides under the MFMA phases and no VGPR is spent on staging.
 //  * S^T = K . Q^T on v_mfma_i32_32x32x32_i8 (A = K tile rows from LDS via ds_read_b128, B = Q^T held in
 //    registers for the whole kernel).  With this orientation every lane owns ONE query row
 //    (column of S^T): 32 of the 64 scores of its row sit in its own registers, the other 32 in
