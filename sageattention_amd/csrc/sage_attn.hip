@@ -1272,9 +1272,12 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;
   // measured on MI355X: D=128 fp16 PV -> one 8-wave workgroup per CU (4-wave: -3 %); D=128 fp8 PV -> two 4-wave
   // workgroups per CU (+3.6 % non-causal, +5.7 % causal); D=64 (<= 168 VGPRs) -> 4-wave workgroups, 3 per CU
-  // ... except for short key sequences (<= 1024 keys: few tiles per workgroup, so prologue and epilogue weigh more and two
-  // smaller workgroups per CU overlap them better): 4-wave +8..10 % at 257-512 keys, +4 % at 1024, -2..3 % from 2048 up
-  const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8 || N <= 1024) ? 4 : 8);
+  // ... except for short key sequences (few tiles per workgroup, so prologue and epilogue weigh more and two smaller
+  // workgroups per CU overlap them better).  Re-measured at the end of round 2 (the prologue now issues its tile copies
+  // first): 4-wave +10 % at 1024 keys, +7 % at 1536, +6 % at 2048, 0 % at 3072-4096, -2 % from 6144; causal (a row attends
+  // half the keys on average) +21 % at 2048, +13 % at 4096, 0 % at 8192, -1 % at 16384 -> 4 waves up to 2048 keys per row.
+  const int keys_per_row = is_causal ? N / 2 : N;
+  const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8 || keys_per_row <= 2048) ? 4 : 8);
   p.nqb = (M + nw * 32 - 1) / (nw * 32);
 #define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
   if (nw == 8) return D == 64 ? SAGE_GO(64, 8) : SAGE_GO(128, 8);

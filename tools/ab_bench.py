@@ -20,7 +20,7 @@ a = ap.parse_args()
 B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, False), "c3c": (4, 32, 8192, 128, True),
                       "c2c": (4, 32, 2048, 64, True), "c16k": (2, 32, 16384, 128, False),
                       "d64_8k": (4, 32, 8192, 64, False), "c3s": (1, 32, 8192, 128, False), "c3xs": (1, 8, 8192, 128, False),
-                      "c3l": (8, 32, 8192, 128, False), "d128_1k": (16, 32, 1024, 128, False), "d128_2kc": (8, 32, 2048, 128, True),
+                      "c3l": (8, 32, 8192, 128, False), "d128_1k": (16, 32, 1024, 128, False), "d128_1536": (8, 32, 1536, 128, False), "d128_2k": (8, 32, 2048, 128, False), "d128_3k": (4, 32, 3072, 128, False), "d128_4kc": (4, 32, 4096, 128, True), "d128_4k": (4, 32, 4096, 128, False), "d128_6k": (4, 32, 6144, 128, False), "c16kc": (2, 32, 16384, 128, True), "d128_2kc": (8, 32, 2048, 128, True),
                       "c4": (4, 32, 16384, 128, True)}[a.wl]
 torch.manual_seed(0)
 DT = torch.float16 if a.dtype == "fp16" else torch.bfloat16
