@@ -370,6 +370,21 @@ void attn_i8_kernel(const AttnParams p) {
   // (head_dim 128 fp16 -3 %, fp8 -0.7 %; head_dim 64 fp16 -9 %, fp8 -7 %): the chip is power limited and an extra MFMA
   // per P operand costs more clock than the 32 v_add_f32 it replaces.
   float l_run = 0.f;
+  // FP16 PV at head_dim 64: the row sum runs on the matrix pipe instead.  v_mfma_f32_4x4x4_16b_f16 with A = ones and
+  // B = four packed fp16 p of the lane (16 blocks of 4 lanes, every lane its own column) adds those four values to an
+  // fp32 accumulator: one 8-cycle MFMA per 4 scores replaces 4 v_add_f32 (16 cycles of the vector issue port).  It sums
+  // the ROUNDED P -- exactly what the reference's fp16 CUDA kernel does (ComputeUnit::kTensorCore: mma::rowsum_f16f16f32
+  // on the packed half P, attn_utils.cuh:528-548, qk_int_sv_f16_cuda_sm80.cu:318-320,814), where its Triton twin sums the
+  // fp32 p.  At head_dim 64 the loop is bound by vector issue and the matrix pipe is a third busy: C2 +4.3 %, C2-causal
+  // +4.1 %, (4,32,8192,64) +1.3 %, and the unrounded p are dead after the convert (153-156 registers instead of 162-168).
+  // At head_dim 128 every gap already holds a P.V MFMA and the small one queues behind it: C3 -1.5 % -- not used there.
+  constexpr bool MROW = !PV_FP8 && (D == 64 ? !abl::kValuRowSum64 : abl::kMfmaRowSum128);
+  v4f l4 = {0.f, 0.f, 0.f, 0.f};  // all four rows of the lane's block hold the same sum
+  v4h ones4 = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+  if constexpr (MROW) asm volatile("" : "+v"(ones4));  // resident: as a constant it is re-materialised per use
+  auto rowsum4 = [&](const v4h ph) __attribute__((always_inline)) {
+    l4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, ph, l4, 0, 0, 0);
+  };
   // The int32 accumulator of S^T starts at the BIT PATTERN of 1.5*2^23: for |S| < 2^22 (|S| <= 128*127^2) the
   // accumulated integer, reinterpreted as fp32, IS the float 12582912 + S exactly, so the logit needs no
   // v_cvt_f32_i32: t - m = fma(as_float(acc), scale, -(12582912*scale + m)).
@@ -567,6 +582,7 @@ void attn_i8_kernel(const AttnParams p) {
       m_run = m_new;
       m_thr = m_new + kLazyThr;
       l_run *= alpha;
+      if constexpr (MROW) l4 *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -603,9 +619,12 @@ void attn_i8_kernel(const AttnParams p) {
             const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
             pf[e] = ph[0];
             pf[e + 1] = ph[1];
-            l_run += pp[0];
-            l_run += pp[1];
+            if constexpr (!MROW) {
+              l_run += pp[0];
+              l_run += pp[1];
+            }
           }
+          if constexpr (MROW) { rowsum4(pf.s0123); rowsum4(pf.s4567); }
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const char* base = v_rd[dt] + (vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D));
@@ -912,10 +931,21 @@ void attn_i8_kernel(const AttnParams p) {
         const v2h ph = __builtin_convertvector(two, v2h);  // v_cvt_pk_f16_f32, RNE
         pf[2 * pr] = ph[0];
         pf[2 * pr + 1] = ph[1];
-        pp[2 * pr] = two[0];
-        pp[2 * pr + 1] = two[1];
+        if constexpr (!MROW) {
+          pp[2 * pr] = two[0];
+          pp[2 * pr + 1] = two[1];
+        }
       };
-      auto p_sum = [&](const int pr) __attribute__((always_inline)) { l_run += pp[2 * pr]; l_run += pp[2 * pr + 1]; };
+      // row sum of pair `pr` of the quarter whose packed P is `vec` (MROW: one MFMA per two pairs, after the odd one)
+      auto p_sum = [&](const int pr, const v8h& vec) __attribute__((always_inline)) {
+        if constexpr (MROW) {
+          if (pr == 1) rowsum4(vec.s0123);
+          if (pr == 3) rowsum4(vec.s4567);
+        } else {
+          l_run += pp[2 * pr];
+          l_run += pp[2 * pr + 1];
+        }
+      };
 #define SAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
       v4i kf = kf_early;
       v8h vf[DT], vn[DT], pf, pn;
@@ -930,7 +960,7 @@ void attn_i8_kernel(const AttnParams p) {
         for (int dt = g * (DT / SPR); dt < (g + 1) * (DT / SPR); ++dt) vf[dt] = v_frag(0, dt);
 #pragma unroll
         for (int pr = g * (4 / SPR); pr < (g + 1) * (4 / SPR); ++pr) {
-          if (pr > 0) p_sum(pr - 1);
+          if (pr > 0) p_sum(pr - 1, pf);
           p_pair(0, pr, pf);
         }
         SAGE_FENCE();
@@ -945,7 +975,7 @@ void attn_i8_kernel(const AttnParams p) {
           vn[dt] = v_frag(q, dt);
 #pragma unroll
           for (int pr = dt * PPG; pr < (dt + 1) * PPG; ++pr) {
-            p_sum(pr == 0 ? 3 : pr - 1);  // the pair computed one step earlier (pair 3 of the previous quarter first)
+            p_sum(pr == 0 ? 3 : pr - 1, pr == 0 ? pf : pn);  // the pair computed one step earlier (pair 3 of the previous quarter first)
             p_pair(q, pr, pn);
           }
           SAGE_FENCE();
@@ -961,7 +991,7 @@ void attn_i8_kernel(const AttnParams p) {
         for (int dt = 0; dt < DT; ++dt) vf[dt] = vn[dt];
       }
       // tail: P.V of quarter 3 beside the row max of S(j+1)
-      p_sum(3);
+      p_sum(3, pf);
       if constexpr (NEXT == 1) { if (j + 1 >= n_plain) mask_limit(j + 1, sb); }
       int mxa = sb[0][0], mxb = sb[0][2];
 #pragma unroll
@@ -1101,7 +1131,7 @@ void attn_i8_kernel(const AttnParams p) {
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
-  const float l_tot = swap_sum(l_run);
+  const float l_tot = swap_sum(MROW ? l4[0] : l_run);
   const float inv = 1.0f / l_tot;
   if (row_l < M_) {
     uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row_l * p.osn;

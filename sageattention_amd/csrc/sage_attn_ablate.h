@@ -99,6 +99,17 @@ SAGE_ABL_FLAG(kCTemp, true);
 #else
 SAGE_ABL_FLAG(kCTemp, false);
 #endif
+// Row sums of the fp16 P on v_mfma_f32_4x4x4_16b_f16 (see the kernel): the product does this at head_dim 64 only
+#ifdef SAGE_EXP_MFMA_ROWSUM_D128     // ... also at head_dim 128 (measured: C3 -1.5 %, C3-causal -1.6 %)
+SAGE_ABL_FLAG(kMfmaRowSum128, true);
+#else
+SAGE_ABL_FLAG(kMfmaRowSum128, false);
+#endif
+#ifdef SAGE_EXP_VALU_ROWSUM_D64      // ... nowhere: the round-1/2 form, 32 v_add_f32 of the unrounded p per tile
+SAGE_ABL_FLAG(kValuRowSum64, true);
+#else
+SAGE_ABL_FLAG(kValuRowSum64, false);
+#endif
 #undef SAGE_ABL_FLAG
 
 }  // namespace abl

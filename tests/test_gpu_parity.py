@@ -78,7 +78,10 @@ def test_attention_kernel_vs_reference_and_oracle(sa, golden, gran):
     """Same int8 tensors and scales the reference kernel consumed (fixtures).
     vs the reference's output: |do| <= 4e-3 (fp16) / 2e-2 (bf16) and calc_diff <= 1e-5 -- the reference rounds every
     tile's PV to fp16, this kernel accumulates in fp32 (see tests/test_oracle_golden.py).
-    vs the oracle restating THIS kernel's arithmetic: <= 2 ulps of the output dtype; LSE <= 5e-4 (base 2)."""
+    vs the oracle restating THIS kernel's arithmetic: <= 2 ulps of the output dtype; LSE <= 5e-4 (base 2) -- 1.5e-3 at
+    head_dim 64, where the row sums are taken from the fp16-ROUNDED P (4x4x4 MFMA, like the reference's CUDA kernel,
+    attn_utils.cuh:528-548): a row with a handful of keys carries the 2^-11 relative rounding of its largest p into l
+    (7e-4 in the base-2 exponent), and the kernel's lazily rescaled p rounds at other points than the oracle's."""
     from oracle import sage_oracle as O
     g, m = golden, golden.meta
     if gran == "per_thread" and m["causal"]:
@@ -91,9 +94,10 @@ def test_attention_kernel_vs_reference_and_oracle(sa, golden, gran):
     if ref_o is not None:
         assert (o - ref_o).abs().max() < (4e-3 if g.dtype == torch.float16 else 2e-2)
         assert calc_diff(o, ref_o) < 1e-5
-        # fp32 sum of unrounded p in both; the kernel's folded dequantisation constant is rounded to <= 0.75 LSB of
-        # the integer score (~1e-4 in the base-2 exponent)
-        assert (lse2 - ref_lse).abs().max() < 5e-4
+        # head_dim 128: fp32 sum of unrounded p in both; the kernel's folded dequantisation constant is rounded to
+        # <= 0.75 LSB of the integer score (~1e-4 in the base-2 exponent).  head_dim 64: l from the rounded P (docstring)
+        lse_tol = 1.5e-3 if g.q.shape[-1] <= 64 else 5e-4
+        assert (lse2 - ref_lse).abs().max() < lse_tol
     if gran == "per_block":
         q8, qs, k8, ks, mult = g.pb_q8, g.pb_qs, g.pb_k8, g.pb_ks, 1.0
     else:
@@ -103,8 +107,8 @@ def test_attention_kernel_vs_reference_and_oracle(sa, golden, gran):
                               out_dtype=g.dtype, flavor="hip")
     ulp = 2.0 ** -10 if g.dtype == torch.float16 else 2.0 ** -7
     assert ((o - oo.float()).abs() <= 2 * ulp * oo.float().abs().clamp(min=0.25)).all(), (o - oo.float()).abs().max()
-    # LSE (base 2): fp32 sum of unrounded p; the folded dequantisation constant adds <= 0.75 LSB of the integer score
-    assert (lse2 - ol).abs().max() < 5e-4
+    # LSE (base 2): the folded dequantisation constant adds <= 0.75 LSB of the integer score (+ docstring at head_dim 64)
+    assert (lse2 - ol).abs().max() < (1.5e-3 if g.q.shape[-1] <= 64 else 5e-4)
 
 
 @pytest.mark.parametrize("gran", ["per_warp", "per_thread"])
