@@ -1135,33 +1135,48 @@ void attn_i8_kernel(const AttnParams p) {
   const float inv = 1.0f / l_tot;
   if (row_l < M_) {
     uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row_l * p.osn;
+    // A lane holds runs of 4 output channels (8 B); lane ^ 32 holds the neighbouring run of the same row.  The two halves
+    // exchange words (v_permlane32_swap) so that each stores 16 contiguous bytes: 8 global_store_dwordx4 per lane instead
+    // of 16 dwordx2 (the store tail of a workgroup is bound by the number of store instructions, not by bytes).
     auto store_rows = [&](auto has_vm) __attribute__((always_inline)) {
       const float* vmp = p.v_mean + ((int64_t)b * p.Hk + hk) * D;
+      auto run4 = [&](const int dt, const int g4) __attribute__((always_inline)) -> uint2 {
+        const int d0 = 32 * dt + 8 * g4 + 4 * hh_l;
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = acc_o[dt][4 * g4 + e] * inv;
+        if constexpr (PV_FP8) {  // fuse_v_scale (qk_int_sv_f8_cuda_sm89.cuh:578-626)
+          const float4 vs = *reinterpret_cast<const float4*>(p.v_scale + ((int64_t)b * p.Hk + hk) * D + d0);
+          x[0] *= vs.x; x[1] *= vs.y; x[2] *= vs.z; x[3] *= vs.w;
+        }
+        if constexpr (decltype(has_vm)::value) {
+          const float4 vmv = *reinterpret_cast<const float4*>(vmp + d0);
+          x[0] += vmv.x; x[1] += vmv.y; x[2] += vmv.z; x[3] += vmv.w;
+        }
+        uint2 w;
+        if (p.out_bf16) {
+          w.x = (uint32_t)f32_to_elem_bits<true>(x[0]) | ((uint32_t)f32_to_elem_bits<true>(x[1]) << 16);
+          w.y = (uint32_t)f32_to_elem_bits<true>(x[2]) | ((uint32_t)f32_to_elem_bits<true>(x[3]) << 16);
+        } else {
+          w.x = (uint32_t)f32_to_elem_bits<false>(x[0]) | ((uint32_t)f32_to_elem_bits<false>(x[1]) << 16);
+          w.y = (uint32_t)f32_to_elem_bits<false>(x[2]) | ((uint32_t)f32_to_elem_bits<false>(x[3]) << 16);
+        }
+        return w;
+      };
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int d0 = 32 * dt + 8 * g4 + 4 * hh_l;
-          float x[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = acc_o[dt][4 * g4 + e] * inv;
-          if constexpr (PV_FP8) {  // fuse_v_scale (qk_int_sv_f8_cuda_sm89.cuh:578-626)
-            const float4 vs = *reinterpret_cast<const float4*>(p.v_scale + ((int64_t)b * p.Hk + hk) * D + d0);
-            x[0] *= vs.x; x[1] *= vs.y; x[2] *= vs.z; x[3] *= vs.w;
+        for (int gp = 0; gp < 2; ++gp) {
+          // runs A (g4 = 2gp) and B (g4 = 2gp+1): the low half-wave keeps both halves of A, the high one both halves of B
+          const uint2 wa = run4(dt, 2 * gp), wb = run4(dt, 2 * gp + 1);
+          if (p.o_vec16) {  // (a row and its lane ^ 32 twin are both inside or both outside the `row < M` guard)
+            const auto sx = __builtin_amdgcn_permlane32_swap(wa.x, wb.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(wa.y, wb.y, false, false);
+            *reinterpret_cast<uint4*>(op + 32 * dt + 16 * gp + 8 * hh_l) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          } else {          // output rows that are only 8-byte aligned: the runs as they are
+            *reinterpret_cast<uint2*>(op + 32 * dt + 16 * gp + 4 * hh_l) = wa;
+            *reinterpret_cast<uint2*>(op + 32 * dt + 16 * gp + 8 + 4 * hh_l) = wb;
           }
-          if constexpr (decltype(has_vm)::value) {
-            const float4 vmv = *reinterpret_cast<const float4*>(vmp + d0);
-            x[0] += vmv.x; x[1] += vmv.y; x[2] += vmv.z; x[3] += vmv.w;
-          }
-          uint2 w;
-          if (p.out_bf16) {
-            w.x = (uint32_t)f32_to_elem_bits<true>(x[0]) | ((uint32_t)f32_to_elem_bits<true>(x[1]) << 16);
-            w.y = (uint32_t)f32_to_elem_bits<true>(x[2]) | ((uint32_t)f32_to_elem_bits<true>(x[3]) << 16);
-          } else {
-            w.x = (uint32_t)f32_to_elem_bits<false>(x[0]) | ((uint32_t)f32_to_elem_bits<false>(x[1]) << 16);
-            w.y = (uint32_t)f32_to_elem_bits<false>(x[2]) | ((uint32_t)f32_to_elem_bits<false>(x[3]) << 16);
-          }
-          *reinterpret_cast<uint2*>(op + d0) = w;
         }
     };
     if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
@@ -1297,6 +1312,7 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   p.msb = mask ? mask_strides[0] : 0; p.msh = mask ? mask_strides[1] : 0; p.msm = mask ? mask_strides[2] : 0; p.msn = mask ? mask_strides[3] : 0;
   p.k_tile_bytes = (int)k_tile; p.v_tile_bytes = (int)v_tile; p.ks_b = ks_b; p.ks_h = ks_h; p.ks_t = (int)ks_t;
   p.kv_tiled = tiled ? 1 : 0;
+  p.o_vec16 = (o->stride_b % 8 == 0 && o->stride_h % 8 == 0 && o->stride_n % 8 == 0) ? 1 : 0;  // 16-byte aligned output rows
   p.q_f16 = fusedq ? (const uint16_t*)q8->data : nullptr;
   p.km = (const uint16_t*)km; p.q_bf16 = q_dtype == SAGE_BF16; p.sm_scale = sm_scale;
   const bool kthread = qk_gran == SAGE_GRAN_PER_THREAD, vb = v_dtype == SAGE_BF16;

@@ -43,6 +43,7 @@ struct AttnParams {
   int64_t ks_b, ks_h;
   int ks_t;
   int kv_tiled;  // non-default tile strides
+  int o_vec16;   // every output row starts on a 16-byte boundary (all strides multiples of 8 elements): 16-byte stores
 };
 
 // v_max_f32 on values that are never signalling NaNs: fmaxf() makes hipcc canonicalise both operands first
