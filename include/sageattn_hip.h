@@ -139,8 +139,9 @@ int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D
  * qk_int8_sv_f16_accum_f16_attn_inst_buf, qk_int8_sv_f16_accum_f16_fuse_v_mean_attn
  * (csrc/qattn/attn_cuda_sm80.h:19-65, qk_int_sv_f16_cuda_sm80.cu:674-1379).  On gfx950 the PV
  * MFMA accumulates in fp32 for every pv_accum_dtype the reference names.
- *   q8 [B,Hq,M,D] int8, k8 [B,Hk,N,D] int8, v [B,Hk,N,D] fp16 (or bf16, converted on the fly as
- *   core.py:633 `v.to(float16)`), o [B,Hq,M,D] fp16/bf16 (o_dtype).
+ *   q8 [B,Hq,M,D] int8, k8 [B,Hk,N,D] int8, v [B,Hk,N,D] fp16 or bf16 (v_dtype), o [B,Hq,M,D] fp16/bf16 (o_dtype).
+ *   A bf16 v is used as it is: P is rounded to bf16 and P.V runs on the bf16 MFMA with fp32 accumulation (the reference
+ *   converts v to fp16 first, core.py:633 `v.to(float16)`; a caller who wants exactly that passes the converted tensor).
  *   q_scale / k_scale: fp32 [B,Hq,Gq] / [B,Hk,Gk] with the shapes sage_quant_qk_int8 produces for
  *   (gran, blkq, warpq, blkk=64, warpk=64)  (…sm80.cu:796-805).
  *   sm_scale: logits are multiplied by sm_scale*log2(e) inside the kernel (…sm80.cu:92); must be

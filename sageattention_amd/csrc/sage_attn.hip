@@ -26,7 +26,9 @@ namespace sage {
 // K/V slots of the LDS tile ring (see the kernel): 4 for the FP8-PV loop where every wave copies a full share of each tile
 constexpr int attn_ring_slots(int D, int nwaves, bool pv_fp8) { return (pv_fp8 && nwaves * 64 <= 4 * D) ? 4 : 2; }
 
-// PV_FP8 = false: V fp16 [N][D] row major (bf16 converted on the fly), PV on v_mfma_f32_32x32x16_f16.
+// PV_FP8 = false: V fp16 [N][D] row major, PV on v_mfma_f32_32x32x16_f16.  V_BF16: V stays bf16 -- P is packed to bf16
+//                 (v_cvt_pk_bf16_f32) and P.V runs on v_mfma_f32_32x32x16_bf16, so the tile is staged and read exactly
+//                 like an fp16 one and nothing is converted (the reference converts V to fp16 first, core.py:633).
 // PV_FP8 = true : V^T OCP e4m3 [D][Npad] in MFMA token order (sage_fp8.hip), PV on the MX-scaled
 //                 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the fp16 rate), P in e4m3.
 template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8, bool HAS_MASK>
@@ -244,15 +246,9 @@ void attn_i8_kernel(const AttnParams p) {
   // base + 16*lane), so the bank swizzle of the tile image is applied to the per-lane SOURCE offset instead:
   // LDS chunk position c of a tile holds global chunk (row(c), pos(c) ^ swizzle(row)).  No VGPR staging, no
   // ds_write, and the copy has a whole iteration to land (it is drained by the vmcnt(0) of the next barrier).
-  // bf16 V needs the fp16 conversion of core.py:633.
-  //   head_dim 64 : the tile is copied raw like an fp16 one, and once the wave's own copies have landed (vmcnt(0)) it
-  //                 converts exactly the 1 KiB slices it copied, IN PLACE, in front of the barrier that publishes the tile:
-  //                 no registers held across the iteration, so the bf16 variants keep the 168 registers / three waves per
-  //                 SIMD of the fp16 ones (register path: 178-181, two waves; C2 in bf16 +7.5 %, causal +12 %).
-  //   head_dim 128: register path (global -> VGPRs at the top of the iteration, convert + ds_write at its end).  Occupancy
-  //                 is two waves either way, and the extra LDS round trip of the in-place form costs 2-7 % there.
-  constexpr bool V_REG = V_BF16 && D == 128;
-  constexpr bool V_INPLACE = V_BF16 && D == 64;
+  // bf16 V is staged like fp16 V (16-bit elements; the transposing LDS read does not care) and multiplied as bf16.
+  // History: rounds 1-2 converted the tile to fp16 on the way (head_dim 128: through registers, head_dim 64: in place in
+  // LDS by the wave that copied the slice), which cost 5-8 % at head_dim 128 and 15-18 % at head_dim 64 against fp16 V.
   int k_voff[KC], v_voff[VC];
 #pragma unroll
   for (int i = 0; i < KC; ++i) {
@@ -265,20 +261,8 @@ void attn_i8_kernel(const AttnParams p) {
     if constexpr (PV_FP8) {
       v_voff[i] = vr * (int)p.vsn + ((pos ^ ((vr >> 2) & 3)) << 4);  // V^T row vr (= channel), 16-B chunk swizzle
     } else {
-      const int cc = V_REG ? pos : ((((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3));
+      const int cc = (((pos >> 2) ^ v_win_swz<D>(vr)) << 2) | (pos & 3);
       v_voff[i] = (vr * (int)p.vsn + cc * 8) * 2;
-    }
-  }
-  typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vg), 0, (int)v_bytes, 0x00020000);
-  (void)v_rsrc;
-  u32x4 vreg[V_REG ? VC : 1];
-  int v_wr[V_REG ? VC : 1];
-  if constexpr (V_REG) {
-#pragma unroll
-    for (int i = 0; i < VC; ++i) {
-      const int c = tid + i * T, vr = c / VCH, cc = c % VCH;
-      v_wr[i] = vr * (2 * D) + ((((cc >> 2) ^ v_win_swz<D>(vr))) << 6) + ((cc & 3) << 4);
     }
   }
   // K(j) -> K buffer `buf`
@@ -289,55 +273,17 @@ void attn_i8_kernel(const AttnParams p) {
       if (KC * T == 64 * KCH || wave * 64 + i * T < 64 * KCH)
         lds_dma16(k_rsrc, (unsigned)(buf * KBYTES + (wave * 64 + i * T) * 16), k_voff[i], j * k_tile_stride);
   };
-  // V(j) -> V buffer `buf` (DMA), or -> registers (V_REG; written to LDS by finish_tile)
+  // V(j) -> V buffer `buf`
   auto load_v = [&](int j, const int buf) __attribute__((always_inline)) {
     if constexpr (abl::kSameTile) j = 0;
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
       if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
-      if constexpr (V_REG)
-        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff[i], j * v_tile_stride, 0);
-      else
-        lds_dma16(v_rsrc_dma, (unsigned)(RING * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
+      lds_dma16(v_rsrc_dma, (unsigned)(RING * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
     }
   };
-  auto bf16x8_to_f16x8 = [&](u32x4 u) __attribute__((always_inline)) -> u32x4 {
-    float f[8];
-    unpack8<true>(make_uint4(u[0], u[1], u[2], u[3]), f);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      u[e] = (uint32_t)f32_to_elem_bits<false>(f[2 * e]) | ((uint32_t)f32_to_elem_bits<false>(f[2 * e + 1]) << 16);
-    return u;
-  };
-  // End of a two-slot iteration, in front of the barrier that publishes K/V buffer contents: every copy of this wave has
-  // landed, and (bf16 V, if `has_v`) the tile in V buffer `buf` is fp16.
-  auto finish_tile = [&](const int buf, const bool has_v) __attribute__((always_inline)) {
-    if constexpr (V_REG) {
-      if (has_v) {
-#pragma unroll
-        for (int i = 0; i < VC; ++i) *reinterpret_cast<u32x4*>(v_lds + buf * VBYTES + v_wr[i]) = bf16x8_to_f16x8(vreg[i]);
-      }
-      dma_wait_all();
-    } else {
-      dma_wait_all();
-      if constexpr (V_INPLACE) {
-        if (has_v) {
-          // the lane id is re-derived here (2 VALU) instead of keeping an address register alive through the loop: these
-          // variants sit exactly at the 168 registers that allow three waves per SIMD
-          int ln;
-          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-          char* const own = v_lds + buf * VBYTES + (wave * 64 + ln) * 16;
-#pragma unroll
-          for (int i = 0; i < VC; ++i) {
-            if (!(VC * T == VROWS * VCH || wave * 64 + i * T < VROWS * VCH)) continue;
-            u32x4* const ptr = reinterpret_cast<u32x4*>(own + i * T * 16);
-            *ptr = bf16x8_to_f16x8(*ptr);
-            if (i + 1 < VC) __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-  };
+  // End of a two-slot iteration, in front of the barrier that publishes K/V buffer contents: every copy of this wave has landed
+  auto finish_tile = [&](const int, const bool) __attribute__((always_inline)) { dma_wait_all(); };
 
   // ---- lane-constant LDS read offsets
   // (pointers that already include the K / V region base: the fast loops and the generic body then share ONE register per
@@ -378,7 +324,8 @@ void attn_i8_kernel(const AttnParams p) {
   // fp32 p.  At head_dim 64 the loop is bound by vector issue and the matrix pipe is a third busy: C2 +4.3 %, C2-causal
   // +4.1 %, (4,32,8192,64) +1.3 %, and the unrounded p are dead after the convert (153-156 registers instead of 162-168).
   // At head_dim 128 every gap already holds a P.V MFMA and the small one queues behind it: C3 -1.5 % -- not used there.
-  constexpr bool MROW = !PV_FP8 && (D == 64 ? !abl::kValuRowSum64 : abl::kMfmaRowSum128);
+  // (bf16 PV keeps the VALU sums of the unrounded p: a sum of bf16-rounded P would cost the LSE three more bits)
+  constexpr bool MROW = !PV_FP8 && !V_BF16 && (D == 64 ? !abl::kValuRowSum64 : abl::kMfmaRowSum128);
   v4f l4 = {0.f, 0.f, 0.f, 0.f};  // all four rows of the lane's block hold the same sum
   v4h ones4 = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
   if constexpr (MROW) asm volatile("" : "+v"(ones4));  // resident: as a constant it is re-materialised per use
@@ -589,6 +536,15 @@ void attn_i8_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e) acc_o[dt][e] *= alpha;
     }
   };
+  // P pair -> two packed 16-bit values in the element type of V (RNE both), and the P.V MFMA of that type
+  auto pack_p = [&](const v2f two) __attribute__((always_inline)) -> v2h {
+    if constexpr (V_BF16) return __builtin_bit_cast(v2h, __builtin_convertvector(two, v2bf));  // v_cvt_pk_bf16_f32
+    else return __builtin_convertvector(two, v2h);                                              // v_cvt_pk_f16_f32 (fp16_rn)
+  };
+  auto pv_mfma = [&](const v8h a, const v8h b, const v16f c) __attribute__((always_inline)) -> v16f {
+    if constexpr (V_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  };
   // p = exp2(t - m) and O^T += V^T . P^T
   uint32_t bits_cur = 0xffffffffu;  // allow mask of tile j (attn_mask loop only)
   auto softmax_pv = [&](const int j, const int vbuf, const v16i (&s)[2], const float sc0, const float sc1,
@@ -616,7 +572,7 @@ void attn_i8_kernel(const AttnParams p) {
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
             v2f pp = {prob(mt, 8 * sq + e), prob(mt, 8 * sq + e + 1)};
-            const v2h ph = __builtin_convertvector(pp, v2h);  // v_cvt_pk_f16_f32, RNE (fp16_rn)
+            const v2h ph = pack_p(pp);
             pf[e] = ph[0];
             pf[e + 1] = ph[1];
             if constexpr (!MROW) {
@@ -635,7 +591,7 @@ void attn_i8_kernel(const AttnParams p) {
             a.s0123 = __builtin_bit_cast(v4h, lo);
             a.s4567 = __builtin_bit_cast(v4h, hi);
             if constexpr (abl::kNoPV) asm volatile("" ::"v"(a), "v"(pf));
-            else acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, acc_o[dt], 0, 0, 0);
+            else acc_o[dt] = pv_mfma(a, pf, acc_o[dt]);
           }
         }
     } else {
@@ -686,11 +642,10 @@ void attn_i8_kernel(const AttnParams p) {
   static_assert(RING == 2 || (KC * T == 64 * KCH && VC * T == VROWS * VCH), "four-slot ring: every wave copies full shares");
   const int last_tile = ntiles - 1;
   if constexpr (RING == 2) {
-    if constexpr (V_REG) prepare_q();  // register-staged V: the tile's registers and the Q block's do not fit together
     dma_k(0, 0);
     load_v(0, 0);
     if (ntiles > 1) dma_k(1, 1);
-    if constexpr (!V_REG) prepare_q();
+    prepare_q();
     finish_tile(0, true);
   } else {
     // K(0..3) and V(0..2), clamped to the last tile so that every wave issues the same number of copies whatever the
@@ -928,7 +883,7 @@ void attn_i8_kernel(const AttnParams p) {
         const float sc = g1 ? a1 : a0, cc = g1 ? c1 : c0;
         v2f two = {__builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(sa[mt][e]), sc, cc)),
                    __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(sa[mt][e + 1]), sc, cc))};
-        const v2h ph = __builtin_convertvector(two, v2h);  // v_cvt_pk_f16_f32, RNE
+        const v2h ph = pack_p(two);
         pf[2 * pr] = ph[0];
         pf[2 * pr + 1] = ph[1];
         if constexpr (!MROW) {
@@ -971,7 +926,7 @@ void attn_i8_kernel(const AttnParams p) {
       for (int q = 1; q < 4; ++q) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt], pf, acc_o[dt], 0, 0, 0);
+          acc_o[dt] = pv_mfma(vf[dt], pf, acc_o[dt]);
           vn[dt] = v_frag(q, dt);
 #pragma unroll
           for (int pr = dt * PPG; pr < (dt + 1) * PPG; ++pr) {
@@ -996,7 +951,7 @@ void attn_i8_kernel(const AttnParams p) {
       int mxa = sb[0][0], mxb = sb[0][2];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt], pf, acc_o[dt], 0, 0, 0);
+        acc_o[dt] = pv_mfma(vf[dt], pf, acc_o[dt]);
         if constexpr (NEXT != 2) {
 #pragma unroll
           for (int idx = dt * (32 / DT); idx < (dt + 1) * (32 / DT); ++idx) {
@@ -1089,11 +1044,11 @@ void attn_i8_kernel(const AttnParams p) {
     }
   };
   // The wave's remaining tiles (a successor that may need masking, then its last one).
-  //  * FP16 PV (not the register-staged bf16 V of head_dim 128) and FP8 PV at head_dim 64: the same hand-placed stream with
+  //  * FP16 / BF16 PV and FP8 PV at head_dim 64: the same hand-placed stream with
   //    run-time slots (fast_iter, NEXT = 1 / 2): C2 +0.8 %, C2-fp8 +1.6 %, (8,32,2048,128) causal +3.5 %.
-  //  * FP8 PV at head_dim 128 and register-staged V: the compiler-scheduled body.  With the stream variants instantiated
+  //  * FP8 PV at head_dim 128: the compiler-scheduled body.  With the stream variants instantiated
   //    their MAIN loop came out 0.3-1 % slower (different register assignment), more than the tail tiles return.
-  constexpr bool STREAM_TAIL = !(V_REG || (PV_FP8 && D == 128));
+  constexpr bool STREAM_TAIL = !(PV_FP8 && D == 128);
   if constexpr (STREAM_TAIL) {
     for (; j + 1 < wave_tiles; ++j) {
       fast_iter(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, j, s_cur, s_nxt, sc0, sc1, nsc0, nsc1);

@@ -21,6 +21,7 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef short v4s_vs __attribute__((__vector_size__(8)));  // operand type of ds_read_tr16_b64
 
 constexpr float kLog2e = 1.4426950408889634f;
