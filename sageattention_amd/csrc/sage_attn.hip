@@ -228,7 +228,7 @@ void attn_i8_kernel(const AttnParams p) {
   const int ntiles = (kv_end + 63) >> 6;
   const int wave_tiles = CAUSAL ? min(ntiles, ((q0 + 31) >> 6) + 1) : ntiles;
 
-  // ---- staging (global -> LDS by LDS-DMA; bf16 V at head_dim 128 through registers).  Buffer addressing: the descriptor holds the (b, h_kv) slice, the
+  // ---- staging (global -> LDS by LDS-DMA).  Buffer addressing: the descriptor holds the (b, h_kv) slice, the
   //      per-thread byte offset is constant for the whole kernel and the tile advance is a scalar offset, so a
   //      tile costs no address VALU; rows >= N fall outside num_records and read as ZERO (V rows beyond the
   //      sequence must be zero: 0 * garbage could be NaN; K rows beyond it are masked in the softmax).
@@ -282,9 +282,6 @@ void attn_i8_kernel(const AttnParams p) {
       lds_dma16(v_rsrc_dma, (unsigned)(RING * KBYTES + buf * VBYTES + (wave * 64 + i * T) * 16), v_voff[i], j * v_tile_stride);
     }
   };
-  // End of a two-slot iteration, in front of the barrier that publishes K/V buffer contents: every copy of this wave has landed
-  auto finish_tile = [&](const int, const bool) __attribute__((always_inline)) { dma_wait_all(); };
-
   // ---- lane-constant LDS read offsets
   // (pointers that already include the K / V region base: the fast loops and the generic body then share ONE register per
   // offset; with integer offsets hipcc kept `base + offset` and `offset` as two live values)
@@ -406,8 +403,8 @@ void attn_i8_kernel(const AttnParams p) {
   // which of the lane's 32 keys of tile j may be attended: bit 16*mt+e.  Sequence end, causal diagonal and the
   // caller's bool attn_mask (False = masked; the reference adds -1e6, which is the same for every row that keeps
   // at least one key; rows with no allowed key at all are undefined there -- they depend on its tile skipping).
-  // attn_mask exists only on the non-causal fp16-PV operator; bf16 V (register-staged, highest register pressure) is
-  // converted to fp16 by the host for masked calls, as the reference does (core.py:289-290)
+  // attn_mask exists only on the non-causal fp16-PV operator with fp16 V: the host converts a bf16 V for masked calls, as the
+  // reference does (core.py:289-290) -- no bf16 instantiation of this rarely used variant
   constexpr bool CAN_MASK = HAS_MASK;  // separate instantiation: the mask bookkeeping must not cost the main variants registers
   const uint8_t* mrow = nullptr;
   if constexpr (CAN_MASK)
@@ -646,7 +643,7 @@ void attn_i8_kernel(const AttnParams p) {
     load_v(0, 0);
     if (ntiles > 1) dma_k(1, 1);
     prepare_q();
-    finish_tile(0, true);
+    dma_wait_all();
   } else {
     // K(0..3) and V(0..2), clamped to the last tile so that every wave issues the same number of copies whatever the
     // sequence length (a clamped copy re-loads the last tile into a slot nobody reads any more); only K(0), V(0), K(1)
@@ -972,7 +969,7 @@ void attn_i8_kernel(const AttnParams p) {
     }
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
-        finish_tile(V_WR, !DYN || j + 1 < ntiles);
+        dma_wait_all();  // two-slot ring: every copy of this wave has landed before the barrier publishes the tiles
       } else if constexpr (DYN) {
         dma_wait_all();  // the last tiles of a wave drain every copy (the counts of the four-slot ring stay constant)
       } else {
@@ -1071,7 +1068,7 @@ void attn_i8_kernel(const AttnParams p) {
       }
       softmax_pv(j, j % RING, s_cur, sc0, sc1, std::true_type{});
       if (has_next) mx_cur = row_max(s_nxt, nsc0, nsc1);
-      finish_tile((j + 1) & 1, j + 1 < ntiles);
+      dma_wait_all();
       __syncthreads();
       s_cur[0] = s_nxt[0]; s_cur[1] = s_nxt[1];
       sc0 = nsc0; sc1 = nsc1;
@@ -1079,7 +1076,7 @@ void attn_i8_kernel(const AttnParams p) {
   }
   for (; j < ntiles; ++j) {
     stage_generic(j);
-    finish_tile((j + 1) & 1, j + 1 < ntiles);
+    dma_wait_all();
     __syncthreads();
   }
 
