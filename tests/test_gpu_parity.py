@@ -416,6 +416,42 @@ def test_bf16_v_is_multiplied_as_bf16(sa, cfg):
     assert (l - l16).abs().max() < (1.5e-3 if D == 64 else 1e-6)
 
 
+@pytest.mark.parametrize("cfg", [(2, 4, 333, 64, False, "fp16"), (1, 4, 520, 128, True, "fp16"), (2, 2, 257, 128, False, "fp8"),
+                                 (1, 4, 192, 64, True, "fp8")])
+def test_output_rows_that_are_only_8_byte_aligned(sa, cfg):
+    """The epilogue stores 16 bytes per lane when every output row starts on a 16-byte boundary (the lane halves exchange
+    4-channel runs first) and keeps 8-byte stores otherwise: an output view whose row stride is a multiple of 4 but not of 8
+    elements must receive exactly the bytes of the contiguous call, and nothing outside its rows."""
+    from sageattention_amd import _lib as L, core
+    B, H, N, D, causal, pv = cfg
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(B, H, N, D, dtype=torch.float16, device="cuda") for _ in range(3))
+    km = sa.quant.k_mean(k)
+    q8, qs, k8, ks, _ = core._quant_qk(q, k, km, "HND", "per_thread", D ** -0.5, 32, False, H, H)
+    lib, st = L.lib(), torch.cuda.current_stream().cuda_stream
+    if pv == "fp8":
+        v8, vsc, _ = sa.quant.per_channel_fp8(v, smooth_v=False)
+        vd = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(1), v8.stride(2))
+
+    def run(o):
+        od = L.SageTensor(o.data_ptr(), o.stride(0), o.stride(1), o.stride(2))
+        if pv == "fp8":
+            r = lib.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, od, L.SAGE_F16, qs.data_ptr(), ks.data_ptr(),
+                                            vsc.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32, D ** -0.5, 0, st)
+        else:
+            r = lib.sage_attn_qk_int8_pv_f16(L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(v, "HND"), L.SAGE_F16, od, L.SAGE_F16,
+                                             qs.data_ptr(), ks.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
+                                             D ** -0.5, 0, st)
+        assert r == 0, r
+    o_ref = torch.empty(B, H, N, D, dtype=torch.float16, device="cuda")
+    run(o_ref)
+    wide = torch.full((B, H, N, D + 4), 7.0, dtype=torch.float16, device="cuda")  # row stride D + 4: 8-byte aligned rows
+    run(wide[..., :D])
+    torch.cuda.synchronize()
+    assert torch.equal(wide[..., :D], o_ref)
+    assert (wide[..., D:] == 7.0).all()
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("cfg", [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8")])
 def test_determinism_under_perturbed_timing(sa, cfg, fused):
