@@ -194,7 +194,8 @@ int sage_attn_fusedq_pv_f8(const sage_tensor* q, int q_dtype, const sage_tensor*
 
 /* ---- attention with an explicit attn_mask ----------------------------------------------------------
  * The attn_mask argument of sageattn_qk_int8_pv_fp16_triton (core.py:249-251,306-318; kernels
- * triton/attn_qk_int8_per_block.py:33-52, attn_qk_int8_per_thread.py:37-75).  Non-causal, FP16 PV.
+ * triton/attn_qk_int8_per_block.py:33-52, attn_qk_int8_per_thread.py:37-75).  Non-causal, 16-bit PV (v fp16 or
+ * bf16, multiplied in its own type exactly as by sage_attn_qk_int8_pv_f16).
  * attn_mask: device pointer to a [B,Hq,M,N] VIEW given by mask_strides[4] in ELEMENTS (host array; 0 =
  * broadcast dimension).  mask_kind 1: bool/uint8, zero = masked (the reference adds -1e6 to the base-2
  * logit); 2: fp16, 3: bf16 additive mask, added to the base-2 logit exactly as the reference does (after

@@ -247,8 +247,7 @@ def sageattn_qk_int8_pv_fp16_triton(
             attn_mask = attn_mask.expand((B, Hq, M, N))
         except Exception:
             raise AssertionError(f"attn_mask shape {attn_mask.shape} cannot be broadcast to {(B, Hq, M, N)}")
-        if v.dtype != torch.float16:
-            v = v.to(torch.float16)  # core.py:289-290
+        # (the reference converts a bf16 V to fp16 here, core.py:289-290; this kernel multiplies it as bf16)
         k8, ks, km = _prep_k(k, tensor_layout, "per_block", smooth_k)
         q8, qs, corr = _quant_q(q, km, tensor_layout, "per_block", sm_scale, 32, return_lse, Hq, Hk)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
@@ -256,7 +255,7 @@ def sageattn_qk_int8_pv_fp16_triton(
         kind = 1 if attn_mask.dtype == torch.bool else (2 if attn_mask.dtype == torch.float16 else 3)
         strides = (ctypes.c_int64 * 4)(*attn_mask.stride())
         L.check(L.lib().sage_attn_qk_int8_pv_f16_masked(
-            L.desc(q8, tensor_layout), L.desc(k8, tensor_layout), L.desc(v, tensor_layout), L.SAGE_F16,
+            L.desc(q8, tensor_layout), L.desc(k8, tensor_layout), L.desc(v, tensor_layout), L.dtype_code(v.dtype),
             L.desc(o, tensor_layout), L.dtype_code(dtype), qs.data_ptr(), ks.data_ptr(), attn_mask.data_ptr(), kind, strides,
             L.ptr(lse2), B, Hq, Hk, M, N, D, L.GRAN_PER_BLOCK, 128, 128, float(sm_scale), 1, L.stream_ptr(q.device)),
             "sage_attn_qk_int8_pv_f16_masked")

@@ -37,7 +37,7 @@ template <int D, int NWAVES, bool CAUSAL, bool KTHREAD, bool V_BF16, bool PV_FP8
 __global__ __launch_bounds__(NWAVES * 64, (D == 64 && PV_FP8 && NWAVES == 4 && SAGE_MINWAVES < 3) ? 3 : SAGE_MINWAVES)
 void attn_i8_kernel(const AttnParams p) {
   static_assert(!(PV_FP8 && V_BF16), "fp8 V has no bf16 flavour");
-  static_assert(!HAS_MASK || (!CAUSAL && !PV_FP8 && !V_BF16), "attn_mask: non-causal fp16-PV operator, fp16 V");
+  static_assert(!HAS_MASK || (!CAUSAL && !PV_FP8), "attn_mask: non-causal 16-bit-PV operator");
   constexpr int T = NWAVES * 64;
   constexpr int QB = NWAVES * 32;
   constexpr int KS = D / 32;          // k-steps of the int8 QK^T MFMA
@@ -403,8 +403,8 @@ void attn_i8_kernel(const AttnParams p) {
   // which of the lane's 32 keys of tile j may be attended: bit 16*mt+e.  Sequence end, causal diagonal and the
   // caller's bool attn_mask (False = masked; the reference adds -1e6, which is the same for every row that keeps
   // at least one key; rows with no allowed key at all are undefined there -- they depend on its tile skipping).
-  // attn_mask exists only on the non-causal fp16-PV operator with fp16 V: the host converts a bf16 V for masked calls, as the
-  // reference does (core.py:289-290) -- no bf16 instantiation of this rarely used variant
+  // attn_mask exists only on the non-causal 16-bit-PV operator (fp16 or bf16 V; the reference converts a bf16 V to fp16
+  // for masked calls as well, core.py:289-290)
   constexpr bool CAN_MASK = HAS_MASK;  // separate instantiation: the mask bookkeeping must not cost the main variants registers
   const uint8_t* mrow = nullptr;
   if constexpr (CAN_MASK)
@@ -1153,15 +1153,15 @@ static int launch_attn(const AttnParams& p, bool causal, bool kthread, bool v_bf
     if (p.mask) {  // attn_mask variant (non-causal, fp16 V: checked by run_attn)
       const size_t smem_m = 2 * 64 * D + 2 * 64 * D * 2;
       const dim3 grid_m(p.nqb * p.Hq * p.B), block_m(NWAVES * 64);
-      if (kthread) {
-        auto kern = attn_i8_kernel<D, NWAVES, false, true, false, false, true>;
-        if (!allow_lds((const void*)kern, smem_m)) return SAGE_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);
-      } else {
-        auto kern = attn_i8_kernel<D, NWAVES, false, false, false, false, true>;
-        if (!allow_lds((const void*)kern, smem_m)) return SAGE_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);
-      }
+#define SAGE_LAUNCH_MASKED(K, V)                                                                                   \
+  do {                                                                                                             \
+    auto kern = attn_i8_kernel<D, NWAVES, false, K, V, false, true>;                                                \
+    if (!allow_lds((const void*)kern, smem_m)) return SAGE_ERR_LAUNCH;                                             \
+    hipLaunchKernelGGL(kern, grid_m, block_m, smem_m, st, p);                                                      \
+  } while (0)
+      if (kthread) { if (v_bf16) SAGE_LAUNCH_MASKED(true, true); else SAGE_LAUNCH_MASKED(true, false); }
+      else { if (v_bf16) SAGE_LAUNCH_MASKED(false, true); else SAGE_LAUNCH_MASKED(false, false); }
+#undef SAGE_LAUNCH_MASKED
       return launch_status();
     }
   }
@@ -1201,7 +1201,7 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
                     const int* cu_q = nullptr, const int* cu_k = nullptr, int q_dtype = -1, const void* km = nullptr,
                     const void* mask = nullptr, int mask_kind = 0, const int64_t* mask_strides = nullptr,
                     const sage_kv_layout* kvl = nullptr) {
-  if (mask && (mask_kind < 1 || mask_kind > 3 || !mask_strides || is_causal || pv_fp8 || cu_q || v_dtype != SAGE_F16)) return SAGE_ERR_INVALID_ARGUMENT;
+  if (mask && (mask_kind < 1 || mask_kind > 3 || !mask_strides || is_causal || pv_fp8 || cu_q)) return SAGE_ERR_INVALID_ARGUMENT;
   const bool fusedq = q_dtype >= 0;  // q8 is then the fp16/bf16 query tensor
   if ((cu_q == nullptr) != (cu_k == nullptr)) return SAGE_ERR_INVALID_ARGUMENT;
   if (fusedq) {

@@ -66,6 +66,20 @@ def test_masked_hip_vs_reference(kind):
         # head_dim 64: l is summed from the fp16-rounded P (4x4x4 MFMA row sums, as the reference's CUDA kernel), the
         # reference Triton kernel sums the fp32 p: up to 2^-11 relative in l for rows that keep few keys
         assert (lse.cpu() - rl)[:, :, sel].abs().max() < 1.5e-3
+        # the same call with V given as bf16 (multiplied as bf16, P rounded to bf16): the fixture's fp16 V loses 3 bits on
+        # the way, P another 3 -- within 3e-2 of the reference output; the LSE does not depend on V
+        o_b = torch.empty_like(o)
+        lse_b = torch.empty_like(lse)
+        vb = v.bfloat16()
+        L.lib().sage_set_tuning(0, nw)
+        L.check(L.lib().sage_attn_qk_int8_pv_f16_masked(
+            L.desc(q8, "HND"), L.desc(k8, "HND"), L.desc(vb, "HND"), 1, L.desc(o_b, "HND"), 0, qs.data_ptr(), ks.data_ptr(),
+            mask.data_ptr(), 1 if kind == "bool" else 2, st, lse_b.data_ptr(), 1, 2, 2, M, N, D, 1, 128, 128, D ** -0.5, 1,
+            torch.cuda.current_stream().cuda_stream), "masked bf16")
+        torch.cuda.synchronize()
+        L.lib().sage_set_tuning(0, 0)
+        assert (o_b.cpu().float() - ref)[:, :, sel].abs().max() < 3e-2
+        assert (lse_b.cpu() - rl)[:, :, sel].abs().max() < 1.5e-3
 
 
 @pytest.mark.gpu
