@@ -248,6 +248,12 @@ def main():
             pre_bytes = (q.numel() * 2 + k.numel() * 2 * 2 + q.numel() + k.numel())
             out["prepass"] = {"ms": round(pre_ms, 4), "GBps": round(pre_bytes / (pre_ms * 1e-3) / 1e9, 1),
                               "bound": "hbm", "peak_GBps": 8000}
+            # the same workload with bf16 tensors (what video models run in): a bf16 V is multiplied as bf16
+            # (v_mfma_f32_32x32x16_bf16), nothing is converted -- context, not the metric (the reference benches in fp16)
+            qb, kb, vb = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+            b_ms = time_events(lambda: entry(qb, kb, vb, is_causal=causal, qk_quant_gran=args.gran), args.steps, args.warmup)
+            out["bf16_inputs"] = {"value": round(total_flops / (b_ms * 1e-3) / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(b_ms, 4)}
+            del qb, kb, vb
             if not args.no_fa2:
                 try:
                     from torch.nn.attention import SDPBackend, sdpa_kernel
