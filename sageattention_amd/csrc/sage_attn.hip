@@ -799,7 +799,10 @@ void attn_i8_kernel(const AttnParams p) {
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[2], pend[3], pk, true);
         pb[w] = pk;
       };
-      auto p_sum = [&]() __attribute__((always_inline)) { psum += pend[0]; psum += pend[1]; psum += pend[2]; psum += pend[3]; };
+      auto p_sum = [&]() __attribute__((always_inline)) {
+        psum += pend[0];
+        if constexpr (!abl::kNoRowSumF8) { psum += pend[1]; psum += pend[2]; psum += pend[3]; }
+      };
 #define SAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
       v4i kf = kf_early;
       v8i vf[DT];

@@ -47,6 +47,11 @@ SAGE_ABL_FLAG(kNoLdsV, true);
 #else
 SAGE_ABL_FLAG(kNoLdsV, false);
 #endif
+#ifdef SAGE_ABL_NOROWSUM_F8 // FP8 stream: 8 instead of 32 row-sum adds per tile (what the adds cost: C4 +4 %, D=64 8K +7 %)
+SAGE_ABL_FLAG(kNoRowSumF8, true);
+#else
+SAGE_ABL_FLAG(kNoRowSumF8, false);
+#endif
 #ifdef SAGE_ABL_NOBAR      // fast loop: no per-tile workgroup barrier
 SAGE_ABL_FLAG(kNoBar, true);
 #else
