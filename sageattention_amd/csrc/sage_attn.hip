@@ -313,21 +313,30 @@ void attn_i8_kernel(const AttnParams p) {
   // (head_dim 128 fp16 -3 %, fp8 -0.7 %; head_dim 64 fp16 -9 %, fp8 -7 %): the chip is power limited and an extra MFMA
   // per P operand costs more clock than the 32 v_add_f32 it replaces.
   float l_run = 0.f;
-  // FP16 PV at head_dim 64: the row sum runs on the matrix pipe instead.  v_mfma_f32_4x4x4_16b_f16 with A = ones and
-  // B = four packed fp16 p of the lane (16 blocks of 4 lanes, every lane its own column) adds those four values to an
-  // fp32 accumulator: one 8-cycle MFMA per 4 scores replaces 4 v_add_f32 (16 cycles of the vector issue port).  It sums
-  // the ROUNDED P -- exactly what the reference's fp16 CUDA kernel does (ComputeUnit::kTensorCore: mma::rowsum_f16f16f32
-  // on the packed half P, attn_utils.cuh:528-548, qk_int_sv_f16_cuda_sm80.cu:318-320,814), where its Triton twin sums the
-  // fp32 p.  At head_dim 64 the loop is bound by vector issue and the matrix pipe is a third busy: C2 +4.3 %, C2-causal
-  // +4.1 %, (4,32,8192,64) +1.3 %, and the unrounded p are dead after the convert (153-156 registers instead of 162-168).
-  // At head_dim 128 every gap already holds a P.V MFMA and the small one queues behind it: C3 -1.5 % -- not used there.
+  // FP16 PV at head_dim 64: the row sum runs on the matrix pipe instead -- one v_mfma_f32_16x16x32_f16 per 16-key quarter.
+  // B = the quarter's 8 packed fp16 p of the lane (MFMA column l%16, k group l/16: lanes l and l+32 are the two halves of
+  // query l%16, lanes l+16 and l+48 those of query l%16+16); A[i][k] = 1 iff (k/8) % 2 == i % 2, so the even result rows hold
+  // the full row sum of query l%16 and the odd ones that of query l%16+16: elements 0 / 1 of every lane's fp32 accumulator
+  // (C is elementwise, so the running sums stay private to the lane and are rescaled by its own alpha).  4 MFMAs of 16 cycles
+  // per tile replace 32 v_add_f32 (128 cycles of the vector issue port) and the final lane-half exchange.  It sums the
+  // ROUNDED P -- exactly what the reference's fp16 CUDA kernel does (ComputeUnit::kTensorCore: mma::rowsum_f16f16f32 on the
+  // packed half P, attn_utils.cuh:528-548, qk_int_sv_f16_cuda_sm80.cu:318-320,814), where its Triton twin sums the fp32 p.
+  // At head_dim 64 the loop is bound by vector issue and the matrix pipe is a third busy: steady state C2 +2.7 %, C2-causal
+  // +3.1 %, (4,32,8192,64) +3.0 % against the VALU sums (a first form on v_mfma_f32_4x4x4_16b_f16, 8 per tile, gave +1.5 /
+  // +2.3 / +1.4 %), and the unrounded p are dead after the convert (153-156 registers instead of 162-168).  At head_dim 128
+  // every gap already holds a P.V MFMA: 4x4x4 -1.5 %, this form +0.2 ... +0.8 % -- not worth giving up the exact fp32 sums there.
   // (bf16 PV keeps the VALU sums of the unrounded p: a sum of bf16-rounded P would cost the LSE three more bits)
   constexpr bool MROW = !PV_FP8 && !V_BF16 && (D == 64 ? !abl::kValuRowSum64 : abl::kMfmaRowSum128);
-  v4f l4 = {0.f, 0.f, 0.f, 0.f};  // all four rows of the lane's block hold the same sum
-  v4h ones4 = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
-  if constexpr (MROW) asm volatile("" : "+v"(ones4));  // resident: as a constant it is re-materialised per use
-  auto rowsum4 = [&](const v4h ph) __attribute__((always_inline)) {
-    l4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, ph, l4, 0, 0, 0);
+  v4f l4 = {0.f, 0.f, 0.f, 0.f};
+  v8h sel8;
+  {
+    const _Float16 one = (((lane >> 4) & 1) == (lane & 1)) ? (_Float16)1.0f : (_Float16)0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sel8[e] = one;
+    if constexpr (MROW) asm volatile("" : "+v"(sel8));  // resident: as a known value it is re-materialised per use
+  }
+  auto rowsum8 = [&](const v8h ph) __attribute__((always_inline)) {
+    l4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel8, ph, l4, 0, 0, 0);
   };
   // The int32 accumulator of S^T starts at the BIT PATTERN of 1.5*2^23: for |S| < 2^22 (|S| <= 128*127^2) the
   // accumulated integer, reinterpreted as fp32, IS the float 12582912 + S exactly, so the logit needs no
@@ -577,7 +586,7 @@ void attn_i8_kernel(const AttnParams p) {
               l_run += pp[1];
             }
           }
-          if constexpr (MROW) { rowsum4(pf.s0123); rowsum4(pf.s4567); }
+          if constexpr (MROW) rowsum8(pf);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const char* base = v_rd[dt] + (vbuf * VBYTES + (32 * mt + 16 * sq) * (2 * D));
@@ -891,11 +900,10 @@ void attn_i8_kernel(const AttnParams p) {
           pp[2 * pr + 1] = two[1];
         }
       };
-      // row sum of pair `pr` of the quarter whose packed P is `vec` (MROW: one MFMA per two pairs, after the odd one)
+      // row sum of pair `pr` of the quarter whose packed P is `vec` (MROW: one MFMA per quarter, after its last pair)
       auto p_sum = [&](const int pr, const v8h& vec) __attribute__((always_inline)) {
         if constexpr (MROW) {
-          if (pr == 1) rowsum4(vec.s0123);
-          if (pr == 3) rowsum4(vec.s4567);
+          if (pr == 3) rowsum8(vec);
         } else {
           l_run += pp[2 * pr];
           l_run += pp[2 * pr + 1];
@@ -1086,7 +1094,7 @@ void attn_i8_kernel(const AttnParams p) {
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
-  const float l_tot = swap_sum(MROW ? l4[0] : l_run);
+  const float l_tot = MROW ? (((row_l - q0) & 16) ? l4[1] : l4[0]) : swap_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (row_l < M_) {
     uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row_l * p.osn;

@@ -104,8 +104,8 @@ SAGE_ABL_FLAG(kCTemp, true);
 #else
 SAGE_ABL_FLAG(kCTemp, false);
 #endif
-// Row sums of the fp16 P on v_mfma_f32_4x4x4_16b_f16 (see the kernel): the product does this at head_dim 64 only
-#ifdef SAGE_EXP_MFMA_ROWSUM_D128     // ... also at head_dim 128 (measured: C3 -1.5 %, C3-causal -1.6 %)
+// Row sums of the fp16 P on v_mfma_f32_16x16x32_f16 (see the kernel): the product does this at head_dim 64 only
+#ifdef SAGE_EXP_MFMA_ROWSUM_D128     // ... also at head_dim 128 (measured: C3 +0.2 %, C3-causal +0.8 %; rounded-P sums)
 SAGE_ABL_FLAG(kMfmaRowSum128, true);
 #else
 SAGE_ABL_FLAG(kMfmaRowSum128, false);

@@ -79,7 +79,7 @@ def test_attention_kernel_vs_reference_and_oracle(sa, golden, gran):
     vs the reference's output: |do| <= 4e-3 (fp16) / 2e-2 (bf16) and calc_diff <= 1e-5 -- the reference rounds every
     tile's PV to fp16, this kernel accumulates in fp32 (see tests/test_oracle_golden.py).
     vs the oracle restating THIS kernel's arithmetic: <= 2 ulps of the output dtype; LSE <= 5e-4 (base 2) -- 1.5e-3 at
-    head_dim 64, where the row sums are taken from the fp16-ROUNDED P (4x4x4 MFMA, like the reference's CUDA kernel,
+    head_dim 64, where the row sums are taken from the fp16-ROUNDED P (row-sum MFMA, like the reference's CUDA kernel,
     attn_utils.cuh:528-548): a row with a handful of keys carries the 2^-11 relative rounding of its largest p into l
     (7e-4 in the base-2 exponent), and the kernel's lazily rescaled p rounds at other points than the oracle's."""
     from oracle import sage_oracle as O

@@ -63,7 +63,7 @@ def test_masked_hip_vs_reference(kind):
         ref, rl = g[f"o_{kind}"].float(), g[f"lse2_{kind}"]
         assert (o.cpu().float() - ref)[:, :, sel].abs().max() < 4e-3
         assert calc_diff(o.cpu().float()[:, :, sel], ref[:, :, sel]) < 1e-5
-        # head_dim 64: l is summed from the fp16-rounded P (4x4x4 MFMA row sums, as the reference's CUDA kernel), the
+        # head_dim 64: l is summed from the fp16-rounded P (MFMA row sums, as the reference's CUDA kernel), the
         # reference Triton kernel sums the fp32 p: up to 2^-11 relative in l for rows that keep few keys
         assert (lse.cpu() - rl)[:, :, sel].abs().max() < 1.5e-3
         # the same call with V given as bf16 (multiplied as bf16, P rounded to bf16): the fixture's fp16 V loses 3 bits on
