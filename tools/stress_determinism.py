@@ -13,7 +13,7 @@ if len(sys.argv) > 2:  # "nofuse": Q quantizer as a separate kernel
     sa.core.FUSE_Q_QUANT = sys.argv[2] != "nofuse"
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 gran = sys.argv[4] if len(sys.argv) > 4 else "per_thread"
-dtype = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == "bf16") else torch.float16  # bf16: in-kernel V conversion
+dtype = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == "bf16") else torch.float16  # bf16: V multiplied as bf16 (bf16 MFMA)
 torch.manual_seed(23)
 big = [torch.randn(4, 32, 8192, 128, dtype=torch.float16, device="cuda") for _ in range(3)]
 cfgs = [(4, 32, 2048, 64, True, "fp16"), (4, 32, 2048, 64, True, "fp8"), (4, 32, 2048, 64, False, "fp8"),
