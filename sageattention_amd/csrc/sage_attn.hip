@@ -356,7 +356,9 @@ void attn_i8_kernel(const AttnParams p) {
   // At head_dim 64 a wave that stays within 168 registers runs three to a SIMD; for the FP8-PV and the causal variants
   // the 16 registers are worth more than the moves (measured: fp8 +5 %, causal +7 %; non-causal fp16 -1.5 % without
   // the pin, so that one keeps it).
-  constexpr bool BIAS_RESIDENT = !HAS_MASK && (D == 128 || (!PV_FP8 && !CAUSAL));
+  // (since the MFMA row sums freed the unrounded p, the causal fp16 variants have room for the pin as well: 157-159
+  //  registers, C2-causal +3.7 %; causal bf16 -- VALU row sums -- and FP8 PV stay without it)
+  constexpr bool BIAS_RESIDENT = !HAS_MASK && (D == 128 || (!PV_FP8 && (!CAUSAL || !V_BF16)));
   if constexpr (BIAS_RESIDENT) asm volatile("" : "+v"(bias));
   // First k-step of an S^T chain: acc = bias + K.Q^T.  C is either the resident bias tuple or the MFMA's own destination
   // registers initialised in place (C = D), so the chain never needs a second 16-register tuple.
