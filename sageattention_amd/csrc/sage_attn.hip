@@ -351,14 +351,14 @@ void attn_i8_kernel(const AttnParams p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = kBiasI;
   // keep the 16 bias registers resident: as a known constant the compiler re-materialises them with 8 v_mov_b64 per
-  // tile, and the kernel is bound by the vector issue port (every VALU instruction costs 4 cycles of it).  Not in the
-  // attn_mask instantiation, which has no registers to spare.
-  // At head_dim 64 a wave that stays within 168 registers runs three to a SIMD; for the FP8-PV and the causal variants
-  // the 16 registers are worth more than the moves (measured: fp8 +5 %, causal +7 %; non-causal fp16 -1.5 % without
-  // the pin, so that one keeps it).
-  // (since the MFMA row sums freed the unrounded p, the causal fp16 variants have room for the pin as well: 157-159
-  //  registers, C2-causal +3.7 %; causal bf16 -- VALU row sums -- and FP8 PV stay without it)
-  constexpr bool BIAS_RESIDENT = !HAS_MASK && (D == 128 || (!PV_FP8 && (!CAUSAL || !V_BF16)));
+  // tile (or, in the in-place form below, 16 moves per S chain), and the kernel is bound by the vector issue port (every
+  // VALU instruction costs 4 cycles of it).  Not in the attn_mask instantiation, which has no registers to spare.
+  // History: until the end of round 2 the head_dim-64 FP8-PV and causal variants gave the pin up to stay within the 168
+  // registers of three waves per SIMD (worth more than the moves: fp8 +5 %, causal +7 %).  Since the register diet, the MFMA
+  // row sums and the bf16-native P.V every dispatched head_dim-64 variant fits WITH the pin (153-168 registers, no scratch;
+  // the build fails otherwise): C2-causal +3.7 % (fp16), +3.1 % (bf16), +4.9 % (FP8 PV); C2-fp8 +3.9 %, (4,32,8192,64)-fp8
+  // +4.0 %; bit-identical.
+  constexpr bool BIAS_RESIDENT = !HAS_MASK;
   if constexpr (BIAS_RESIDENT) asm volatile("" : "+v"(bias));
   // First k-step of an S^T chain: acc = bias + K.Q^T.  C is either the resident bias tuple or the MFMA's own destination
   // registers initialised in place (C = D), so the chain never needs a second 16-register tuple.
