@@ -72,8 +72,10 @@ const char* sage_status_string(int status);
 /* Compile-time target of the device code in this library ("gfx950"). */
 const char* sage_target_arch(void);
 
-/* Process-wide tuning knob (speed only, never results).  key SAGE_TUNE_NWAVES: waves per workgroup of the attention
- * kernels, value in {0 = default, 4, 8}. */
+/* Tuning knob of the CALLING HOST THREAD (speed only, never results): it applies to the attention launches this thread
+ * makes afterwards and to no other thread's.  key SAGE_TUNE_NWAVES: waves per workgroup of the attention kernels, value
+ * in {0 = the library's measured choice, 4, 8}.  The one-call operators (sage_sageattn_*) take the same choice per call
+ * in their options struct instead. */
 typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0 } sage_tune_key;
 int sage_set_tuning(int key, int value);
 

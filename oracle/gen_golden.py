@@ -110,12 +110,55 @@ def gen_masked():
     print(f"masked_d64: wrote {os.path.getsize(path)/1024:.0f} KiB", flush=True)
 
 
+def gen_masked_thread():
+    """What the FORK runs for ``sageattn_qk_int8_pv_fp16_triton(quantization_backend="triton", attn_mask=...)``
+    (core.py:295-318): per_thread_int8 + attn_qk_int8_per_thread.forward(..., attn_mask=bool | additive), non-causal.
+    Three cases: head_dim 64 fp16 (M != N, ragged), head_dim 128 fp16 with GQA, head_dim 64 bf16 in NHD layout (V is
+    converted to fp16 first, core.py:289-290); every bool mask has whole 128x64 tiles off (the kernel's tile skip,
+    attn_qk_int8_per_thread.py:40-48) and one fully masked row."""
+    cases = [("pt_masked_d64", 1, 2, 2, 200, 300, 64, "HND", torch.float16, 778),
+             ("pt_masked_d128_gqa", 1, 4, 2, 160, 256, 128, "HND", torch.float16, 779),
+             ("pt_masked_bf16_nhd", 2, 2, 2, 130, 192, 64, "NHD", torch.bfloat16, 780)]
+    for name, B, Hq, Hk, M, N, D, layout, dtype, seed in cases:
+        torch.manual_seed(seed)
+        shp = (lambda h, n: (B, h, n, D)) if layout == "HND" else (lambda h, n: (B, n, h, D))
+        q = torch.randn(shp(Hq, M)).to(dtype)
+        k = (torch.randn(shp(Hk, N)) + 1.5 * torch.randn((1, Hk, 1, D) if layout == "HND" else (1, 1, Hk, D))).to(dtype)
+        v = torch.randn(shp(Hk, N)).to(dtype)
+        km = k.mean(dim=2 if layout == "HND" else 1, keepdim=True)   # core.py:280
+        sm = 1.0 / (D ** 0.5)
+        v16 = v.to(torch.float16)                                    # core.py:289-290
+        q8, qs, k8, ks = per_thread_int8(q, k, km=km, sm_scale=sm, tensor_layout=layout)
+        mb = torch.rand(B, 1, M, N) > 0.3
+        mb[..., :128, 64:192] = False            # whole 128x64 tiles masked out (tile skipping)
+        mb[..., 5, :] = False                    # a fully masked row (undefined in the reference; excluded by the tests)
+        mb = mb.expand(B, Hq, M, N)
+        mf = (torch.randn(B, 1, M, N) * 2).to(dtype).expand(B, Hq, M, N)
+        ob, lb = run_quiet(attn_thread, q8, k8, v16, qs, ks, sm, tensor_layout=layout, attn_mask=mb, output_dtype=dtype,
+                           return_lse=True)
+        of, lf = run_quiet(attn_thread, q8, k8, v16, qs, ks, sm, tensor_layout=layout, attn_mask=mf, output_dtype=dtype,
+                           return_lse=True)
+        meta = dict(B=B, Hq=Hq, Hk=Hk, M=M, N=N, D=D, layout=layout, dtype="fp16" if dtype == torch.float16 else "bf16",
+                    sm_scale=sm)
+        path = os.path.join(OUT, "masked", f"{name}.npz")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        np.savez_compressed(path, q=bits(q), k=bits(k), v=bits(v), km=bits(km), q8=q8.numpy(), k8=k8.numpy(),
+                            qs=qs.numpy(), ks=ks.numpy(), mask_bool=mb[:, 0].contiguous().numpy(),
+                            mask_float=bits(mf[:, 0].contiguous()), o_bool=bits(ob), lse2_bool=lb.numpy(),
+                            o_float=bits(of), lse2_float=lf.numpy(), meta=np.array([repr(meta)]))
+        print(f"{name}: wrote {os.path.getsize(path)/1024:.0f} KiB", flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])   # optional: names of the cases to (re)generate; seeds depend on the case's index only
+    if "pt_masked" in only:
+        gen_masked_thread()
+        return
     if not only:
         gen_varlen()
         gen_masked()
+        gen_masked_thread()
     for i, (name, B, Hq, Hk, M, N, D, layout, dt, causal, kbias) in enumerate(CASES):
         if only and name not in only:
             continue

@@ -81,11 +81,32 @@ def _check_m0_private(obj):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(*parts) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for part in parts:
+        h.update(part if isinstance(part, bytes) else str(part).encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _read(path) -> bytes:
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def _stamp_ok(target, key) -> bool:
+    """A target is current iff it exists and its stamp file holds `key` = a digest of everything it was built from
+    (source text, every header, the compiler flags): a flag change or a header edit rebuilds, a touched file does not."""
+    try:
+        return os.path.exists(target) and _read(target + ".stamp").decode().strip() == key
+    except OSError:
+        return False
+
+
+def _write_stamp(target, key):
+    with open(target + ".stamp", "w") as f:
+        f.write(key + "\n")
 
 
 def build_variant(out: str, extra_flags, verbose: bool = False) -> str:
@@ -110,38 +131,49 @@ def build_variant(out: str, extra_flags, verbose: bool = False) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile what is out of date and link.  The library's stamp covers every source, header and flag, so a snapshot
+    that carries the built .so and its stamp but no objects (the GPU box: *.o stay behind, .gpurunignore) builds nothing."""
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "sageattn_hip.h"))
+    hdr_key = _digest(*[_read(h) for h in hdrs])
+    keys = {src: _digest(HIPCC, ARCH, " ".join(COMMON + extra), _read(os.path.join(CSRC, src)), hdr_key)
+            for src, extra in SOURCES}
+    lib_key = _digest(*[keys[src] for src, _ in SOURCES])
+    if not force and _stamp_ok(LIB, lib_key):
+        return LIB
     objs = []
     procs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or not _stamp_ok(o, keys[src]):
             cmd = [HIPCC] + COMMON + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, pr in procs:
+            procs.append((src, o, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, o, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         try:
             _check_no_scratch(src, out)
             _check_occupancy(src, out)
-            if src == "sage_attn.hip":
-                _check_m0_private(os.path.join(CSRC, "sage_attn.o"))
         except RuntimeError:
-            os.remove(os.path.join(CSRC, src.replace(".hip", ".o")))  # never link (or cache) a spilling object
+            os.remove(o)  # never link (or cache) a spilling object
             raise
+        _write_stamp(o, keys[src])
         if verbose:
             print("\n".join(l for l in out.splitlines() if "remark:" not in l))
-    if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}")
+    # whenever sage_attn.o is LINKED (not only when it was just compiled): nothing but lds_dma16 may touch M0.  The check
+    # is a text search of the disassembly for `m0` operands; instructions that use M0 implicitly (s_movrel*, GWS,
+    # s_sendmsg) would not be caught -- none of them occurs in code hipcc emits for these sources.
+    _check_m0_private(os.path.join(CSRC, "sage_attn.o"))
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    _write_stamp(LIB, lib_key)
     return LIB
 
 

@@ -51,24 +51,11 @@ def _pad_head_dim(q, k, v):
 
 
 def _quant_qk(q, k, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, want_lse_corr, Hq, Hk):
-    """Quantize Q and K (core.py:621-624) and, when asked, produce the LSE correction q.km (core.py:613-617)
-    inside the Q quantizer's pass over Q."""
-    dot_vec = km if (want_lse_corr and km is not None) else None
-    grp = Hq // Hk
-    if qk_quant_gran == "per_block":  # triton path: sm_scale*log2e folded into Q (quant_per_block.py:84)
-        q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_BLOCK, False, 128, 128, sm_scale * 1.44269504, L.ROUND_TRITON,
-                              dot_vec=dot_vec, dot_group=grp, dense_heads=True)
-        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km, dense_heads=True)
-    elif qk_quant_gran == "per_warp":
-        q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_WARP, False, 128, WARPQ, 1.0, L.ROUND_CUDA,
-                              dot_vec=dot_vec, dot_group=grp, dense_heads=True)
-        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_BLOCK, True, 64, 64, 1.0, L.ROUND_CUDA, mean=km, dense_heads=True)
-    elif qk_quant_gran == "per_thread":
-        q8, qs, corr = _quant(q, tensor_layout, L.GRAN_PER_THREAD, False, 128, WARPQ, 1.0, L.ROUND_TRITON,
-                              dot_vec=dot_vec, dot_group=grp, dense_heads=True)
-        k8, ks, _ = _quant(k, tensor_layout, L.GRAN_PER_THREAD, True, 64, 64, 1.0, L.ROUND_TRITON, mean=km, dense_heads=True)
-    else:
-        raise ValueError(f"Unsupported qk_quant_gran: {qk_quant_gran}")
+    """Quantize Q and K with a given mean (core.py:621-624): the pairing tables below, so tests and tools that need
+    pre-quantized operands use exactly what the operators use."""
+    gran, rnd = _k_pairing(qk_quant_gran)
+    k8, ks, _ = _quant(k, tensor_layout, gran, True, 64, 64, 1.0, rnd, mean=km, dense_heads=True)
+    q8, qs, corr = _quant_q(q, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, want_lse_corr, Hq, Hk)
     return q8, qs, k8, ks, corr
 
 
@@ -80,7 +67,8 @@ def _finish_lse(lse2, corr, sm_scale):
     return out
 
 
-_GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_warp": L.GRAN_PER_WARP, "per_thread": L.GRAN_PER_THREAD}
+_GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_block_cuda": L.GRAN_PER_BLOCK, "per_warp": L.GRAN_PER_WARP,
+              "per_thread": L.GRAN_PER_THREAD}
 
 # Fold the Q quantizer into the attention kernel (sage_attn_fusedq_*): same bits, one launch and one pass over Q less.
 # Measured in-process (tools/ab_e2e.py): +2..4 % end to end at (4,32,2048,64), neutral at (4,32,8192,128) where the
@@ -93,10 +81,25 @@ FUSE_Q_QUANT = os.environ.get("SAGEATTN_FUSE_Q", "1") == "1"
 FUSE_Q_MAX_SEQ = 4096
 
 
-_K_QUANT = {"per_block": (L.GRAN_PER_BLOCK, L.ROUND_TRITON), "per_warp": (L.GRAN_PER_BLOCK, L.ROUND_CUDA),
-            "per_thread": (L.GRAN_PER_THREAD, L.ROUND_TRITON)}
-_Q_QUANT = {"per_block": (L.GRAN_PER_BLOCK, L.ROUND_TRITON), "per_warp": (L.GRAN_PER_WARP, L.ROUND_CUDA),
-            "per_thread": (L.GRAN_PER_THREAD, L.ROUND_TRITON)}
+# quantizer pairings of core.py:295-299,621-624: granularity name -> (K granularity, Q granularity, rounding).
+# "per_block" = the Triton quantizer (quant_per_block.py), "per_block_cuda" = csrc/fused (quant.py:23-104, RNE), both with
+# sm_scale*log2e folded into Q.
+_PAIRING = {"per_block": (L.GRAN_PER_BLOCK, L.GRAN_PER_BLOCK, L.ROUND_TRITON),
+            "per_block_cuda": (L.GRAN_PER_BLOCK, L.GRAN_PER_BLOCK, L.ROUND_CUDA),
+            "per_warp": (L.GRAN_PER_BLOCK, L.GRAN_PER_WARP, L.ROUND_CUDA),
+            "per_thread": (L.GRAN_PER_THREAD, L.GRAN_PER_THREAD, L.ROUND_TRITON)}
+
+
+def _pairing(qk_quant_gran):
+    try:
+        return _PAIRING[qk_quant_gran]
+    except KeyError:
+        raise ValueError(f"Unsupported qk_quant_gran: {qk_quant_gran}") from None
+
+
+def _k_pairing(qk_quant_gran):
+    kg, _, rnd = _pairing(qk_quant_gran)
+    return kg, rnd
 
 
 def _prep_k(k, tensor_layout, qk_quant_gran, smooth_k):
@@ -104,7 +107,7 @@ def _prep_k(k, tensor_layout, qk_quant_gran, smooth_k):
     Two passes over K in three launches on purpose: single-pass forms (workgroups of a head exchanging partial sums
     inside one launch; one workgroup per head re-reading out of L2) were built and measured SLOWER on MI355X for every
     shape from 2K keys up (pre-pass) -- K's second read is an L2 / Infinity-Cache hit anyway."""
-    gran, rnd = _K_QUANT[qk_quant_gran]
+    gran, rnd = _k_pairing(qk_quant_gran)
     if smooth_k:
         return k_smooth_quant(k, tensor_layout, gran, rnd)
     km = None
@@ -114,9 +117,9 @@ def _prep_k(k, tensor_layout, qk_quant_gran, smooth_k):
 
 def _quant_q(q, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, want_lse_corr, Hq, Hk):
     """Q half of core.py:621-624 (+ the LSE correction q.km of core.py:613-617 in the same pass) -> (q8, qs, corr)."""
-    gran, rnd = _Q_QUANT[qk_quant_gran]
+    _, gran, rnd = _pairing(qk_quant_gran)
     dot_vec = km if (want_lse_corr and km is not None) else None
-    if qk_quant_gran == "per_block":  # triton path: sm_scale*log2e folded into Q (quant_per_block.py:84)
+    if qk_quant_gran in ("per_block", "per_block_cuda"):  # triton path: sm_scale*log2e folded into Q (quant_per_block.py:84)
         return _quant(q, tensor_layout, gran, False, 128, 128, sm_scale * 1.44269504, rnd, dot_vec=dot_vec,
                       dot_group=Hq // Hk, dense_heads=True)
     return _quant(q, tensor_layout, gran, False, 128, WARPQ, 1.0, rnd, dot_vec=dot_vec, dot_group=Hq // Hk, dense_heads=True)
@@ -162,7 +165,7 @@ def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smoot
         vm = None
         if smooth_v:
             v, vm = sub_mean(v, tensor_layout)
-        if FUSE_Q_QUANT and qk_quant_gran != "per_block" and L.dims(q, tensor_layout)[2] <= FUSE_Q_MAX_SEQ:
+        if FUSE_Q_QUANT and not qk_quant_gran.startswith("per_block") and L.dims(q, tensor_layout)[2] <= FUSE_Q_MAX_SEQ:
             lse = _fused_attn(q, k8, ks, v, o, km, None, vm, tensor_layout, is_causal, qk_quant_gran, WARPQ, sm_scale,
                               return_lse, False)
             o = o[..., :head_dim_og]
@@ -170,7 +173,7 @@ def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smoot
         q8, qs, corr = _quant_q(q, km, tensor_layout, qk_quant_gran, sm_scale, WARPQ, return_lse, Hq, Hk)
         lse2 = _qattn._attn_f16(q8, k8, v, o, qs, ks, vm, 0 if tensor_layout == "NHD" else 1, int(is_causal),
                                 _GRAN_CODE[qk_quant_gran], sm_scale, int(return_lse),
-                                logit_mult_is_one=(qk_quant_gran == "per_block"))
+                                logit_mult_is_one=qk_quant_gran.startswith("per_block"))
         o = o[..., :head_dim_og]
         if return_lse:
             return o, _finish_lse(lse2, corr if smooth_k else None, sm_scale)
@@ -224,15 +227,28 @@ def sageattn_qk_int8_pv_fp16_triton(
     return_lse: bool = False,
     **kwargs: Any,
 ) -> torch.Tensor:
-    """Reference core.py:161-360 (per-block INT8, FP16 PV).  Same numerics contract, served by the HIP kernels:
-    per-block quantization with sm_scale*log2e folded into Q.  ``attn_mask`` (bool, or additive in q's dtype; any shape
-    broadcastable to [B,H,M,N]) follows the reference kernels: False adds -1e6, an additive mask is added to the
-    base-2 logits (attn_qk_int8_per_block.py:33-52)."""
+    """Reference core.py:161-360 (INT8 Q/K, FP16 PV, the reference's Triton kernels), served by the HIP kernels.
+
+    ``quantization_backend`` selects the quantizer pairing the way the fork does (core.py:295-318):
+      * ``"triton"``, non-causal (with or without ``attn_mask``): per-thread quantization (quant_per_thread.py) and the
+        per-thread kernel (attn_qk_int8_per_thread.py); sm_scale*log2e applied in the kernel.
+      * ``"cuda"``: per-block quantization with the CUDA quantizer's rounding (quant.py:23-104, sm_scale*log2e folded
+        into Q) and the per-block kernel.
+      * causal calls keep the upstream per-block pairing (quant_per_block.py + attn_qk_int8_per_block_causal.py) for
+        ``"triton"``: the fork hands per-thread scales to the per-block causal kernel there, which indexes them with
+        per-block strides -- not reproduced.
+    ``attn_mask`` (bool, or additive in q's dtype; any shape broadcastable to [B,H,M,N]) follows the reference kernels:
+    False adds -1e6, an additive mask is added to the base-2 logits (attn_qk_int8_per_thread.py:37-75).  ``sm_scale`` is
+    honoured (the fork's per-thread kernel hard-codes 1/sqrt(padded head_dim), attn_qk_int8_per_thread.py:66)."""
     dtype = _common_checks(q, k, v)
     if quantization_backend not in ("triton", "cuda"):
         raise ValueError(f"Unsupported quantization backend: {quantization_backend}")
+    if quantization_backend == "cuda":
+        gran = "per_block_cuda"
+    else:
+        gran = "per_block" if is_causal else "per_thread"
     if attn_mask is None:
-        return _sage_fp16(q, k, v, tensor_layout, is_causal, "per_block", sm_scale, smooth_k, False, return_lse)
+        return _sage_fp16(q, k, v, tensor_layout, is_causal, gran, sm_scale, smooth_k, False, return_lse)
     # ---- attn_mask (core.py:249-251, 302-318)
     assert attn_mask.dtype == torch.bool or attn_mask.dtype == q.dtype, "attn_mask must be of dtype bool or the same dtype as q."
     assert attn_mask.device == q.device, "All tensors must be on the same device."
@@ -248,17 +264,18 @@ def sageattn_qk_int8_pv_fp16_triton(
         except Exception:
             raise AssertionError(f"attn_mask shape {attn_mask.shape} cannot be broadcast to {(B, Hq, M, N)}")
         # (the reference converts a bf16 V to fp16 here, core.py:289-290; this kernel multiplies it as bf16)
-        k8, ks, km = _prep_k(k, tensor_layout, "per_block", smooth_k)
-        q8, qs, corr = _quant_q(q, km, tensor_layout, "per_block", sm_scale, 32, return_lse, Hq, Hk)
+        k8, ks, km = _prep_k(k, tensor_layout, gran, smooth_k)
+        q8, qs, corr = _quant_q(q, km, tensor_layout, gran, sm_scale, 32, return_lse, Hq, Hk)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         lse2 = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device) if return_lse else None
         kind = 1 if attn_mask.dtype == torch.bool else (2 if attn_mask.dtype == torch.float16 else 3)
         strides = (ctypes.c_int64 * 4)(*attn_mask.stride())
+        per_block = gran != "per_thread"
         L.check(L.lib().sage_attn_qk_int8_pv_f16_masked(
             L.desc(q8, tensor_layout), L.desc(k8, tensor_layout), L.desc(v, tensor_layout), L.dtype_code(v.dtype),
             L.desc(o, tensor_layout), L.dtype_code(dtype), qs.data_ptr(), ks.data_ptr(), attn_mask.data_ptr(), kind, strides,
-            L.ptr(lse2), B, Hq, Hk, M, N, D, L.GRAN_PER_BLOCK, 128, 128, float(sm_scale), 1, L.stream_ptr(q.device)),
-            "sage_attn_qk_int8_pv_f16_masked")
+            L.ptr(lse2), B, Hq, Hk, M, N, D, _GRAN_CODE[gran], 128, 128 if per_block else 32, float(sm_scale),
+            1 if per_block else 0, L.stream_ptr(q.device)), "sage_attn_qk_int8_pv_f16_masked")
         o = o[..., :head_dim_og]
         if return_lse:
             return o, _finish_lse(lse2, corr if smooth_k else None, sm_scale)
@@ -299,7 +316,7 @@ def sageattn_qk_int8_pv_fp8_cuda(
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         if smooth_k and not smooth_v and k.shape == v.shape and k.dtype == v.dtype:
             # the default configuration: K and V prepared by one call (two launches instead of five up to 4096 keys)
-            gran, rnd = _K_QUANT[qk_quant_gran]
+            gran, rnd = _k_pairing(qk_quant_gran)
             k8, ks, km, v8, v_scale = kv_prepare_fp8(k, v, tensor_layout, gran, rnd, scale_max=448.0)
             vm = None
         else:

@@ -681,7 +681,10 @@ void attn_i8_kernel(const AttnParams p) {
     float sc0, sc1;
     for (int j = 0; j < ntiles; ++j) {
       const int buf = j & 1;
-      if (j + 1 < ntiles) { dma_k(j + 1, buf ^ 1); load_v(j + 1, buf ^ 1); }
+      if (j + 1 < ntiles) {
+        if (j > 0) dma_k(j + 1, buf ^ 1);  // K(1) was copied by the prologue
+        load_v(j + 1, buf ^ 1);
+      }
       bits_cur = allow_bits(j);
       if (__builtin_amdgcn_ballot_w64(bits_cur != 0) != 0) {
         tile_scales(j, sc0, sc1);
@@ -1204,7 +1207,9 @@ static bool t_ok(const sage_tensor* t, int align_elems) {
          t->stride_n % align_elems == 0;
 }
 
-int g_nwaves_override = 0;  // tuning hook (sage_set_tuning)
+// tuning hook (sage_set_tuning): per host thread, so a test or tool that pins the geometry for its own calls cannot change
+// the launches of another thread; 0 = the measured default below
+static thread_local int g_nwaves_override = 0;
 
 // shared argument handling of the two attention entry points
 static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
