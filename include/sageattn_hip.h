@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SAGEATTN_HIP_ABI_VERSION 2
+#define SAGEATTN_HIP_ABI_VERSION 3
 
 typedef void* sage_stream_t; /* hipStream_t */
 
@@ -76,8 +76,9 @@ const char* sage_target_arch(void);
  * makes afterwards and to no other thread's.  key SAGE_TUNE_NWAVES: waves per workgroup of the attention kernels, value
  * in {0 = the library's measured choice, 4, 8}.  The one-call operators (sage_sageattn_*) take the same choice per call
  * in their options struct instead. */
-typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0 } sage_tune_key;
+typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0, SAGE_TUNE_MFMA = 1 /* 0 = default, 16 or 32: MFMA fragment family */ } sage_tune_key;
 int sage_set_tuning(int key, int value);
+int sage_get_tuning(int key); /* the calling thread's value; -1 for an unknown key */
 
 /* ---- K smoothing ---------------------------------------------------------------------------
  * km[b,h,:] = mean over n of k[b,h,n,:], fp32 accumulation, one rounding to `dtype`.
@@ -270,6 +271,39 @@ size_t sage_kv_prepare_fp8_workspace_bytes(int B, int H, int N, int D);
 int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, int dtype, int B, int H, int N, int D,
                         const sage_tensor* k_int8, float* k_scale, void* km, int gran, int rounding,
                         const sage_tensor* v_fp8, float* v_scale, float scale_max, void* workspace, sage_stream_t stream);
+
+/* ---- one-call operators ---------------------------------------------------------------------------------------------
+ * The whole body of sageattn_qk_int8_pv_fp16_cuda (core.py:604-651) / sageattn_qk_int8_pv_fp8_cuda (core.py:786-905)
+ * below their argument checks as ONE call with ONE caller-provided workspace: km = mean(k) and the INT8 K quantizer,
+ * the FP8 V^T quantizer (pv_f8), the Q quantizer (folded into the attention kernel's prologue up to 4096 query rows),
+ * the fused attention kernel and the LSE fix of core.py:651.  It sequences the library's own entry points on `stream`
+ * (sage_k_smooth_quant | sage_kv_prepare_fp8, sage_quant_qk_int8, sage_attn_{fusedq,qk_int8}_pv_*, sage_finish_lse), so
+ * results are bit-identical to calling those one by one.  q, k, v, o: fp16 or bf16 (one dtype), head_dim 64 or 128 (the
+ * caller pads, core.py:592-601); lse: optional fp32 [B,Hq,M], receives the natural-log LSE of the un-smoothed logits.
+ * opts: quantization granularity of the reference's `qk_quant_gran` (per_warp -> CUDA quantizer numerics, per_thread ->
+ * Triton numerics, core.py:621-624); warpq 32 (16 = the reference's "fp16+fp32" per-warp variant, core.py:622); smooth_k
+ * must be 1 (core.py:612; without smoothing use the separate entry points); fuse_q -1 = the library's choice; nwaves =
+ * the per-call form of SAGE_TUNE_NWAVES (0 = the library's measured choice).
+ * workspace: at least sage_sageattn_workspace_bytes(...) bytes, 16-byte aligned, private to the call until it has
+ * finished on `stream`. */
+typedef struct sage_op_opts {
+  int qk_gran;  /* SAGE_GRAN_PER_WARP | SAGE_GRAN_PER_THREAD */
+  int warpq;    /* 32 (or 16) */
+  int smooth_k; /* 1 */
+  int fuse_q;   /* -1 | 0 | 1 */
+  int nwaves;   /* 0 | 4 | 8 */
+  int reserved[3];
+} sage_op_opts;
+size_t sage_sageattn_workspace_bytes(int pv_fp8, int B, int Hq, int Hk, int M, int N, int D, int want_lse,
+                                     const sage_op_opts* opts);
+int sage_sageattn_pv_f16(const sage_tensor* q, const sage_tensor* k, const sage_tensor* v, int dtype,
+                         const sage_tensor* o, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal,
+                         float sm_scale, const sage_op_opts* opts, void* workspace, size_t workspace_bytes,
+                         sage_stream_t stream);
+int sage_sageattn_pv_f8(const sage_tensor* q, const sage_tensor* k, const sage_tensor* v, int dtype,
+                        const sage_tensor* o, float* lse, int B, int Hq, int Hk, int M, int N, int D, int is_causal,
+                        float sm_scale, float scale_max, const sage_op_opts* opts, void* workspace,
+                        size_t workspace_bytes, sage_stream_t stream);
 
 /* ==== sequence-parallel building blocks (new: the reference has no parallelism code; its hook is
  * return_lse, core.py:122-124, and its multi-GPU launcher delegates to xDiT, example/parallel_sageattn_cogvideo.py:40-52).

@@ -16,8 +16,10 @@ SOURCES = [
     # packed f32 VALU is slower beside MFMAs; contraction off: the fused Q-quantizer prologue must round exactly like
     # K1 (sage_quant.hip) -- the tile loop spells its fmas out (__builtin_fmaf), so it is unaffected
     ("sage_attn.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
+    ("sage_attn16.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
+    ("sage_op.hip", []),
 ]
 # -Wno-inline-asm: lds_dma16 names M0 in its clobber list, which clang reports as "reserved register" (see the function)
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
@@ -109,12 +111,16 @@ def _write_stamp(target, key):
         f.write(key + "\n")
 
 
-def build_variant(out: str, extra_flags, verbose: bool = False) -> str:
-    """Timing-only variant build (ablations, A/B): separate objects, separate output library."""
+def build_variant(out: str, extra_flags, verbose: bool = False, only=None) -> str:
+    """Timing-only variant build (ablations, A/B): separate objects, separate output library.  `only`: the sources the
+    flags apply to -- the others are linked from the product objects (build() first)."""
     import tempfile
     tmp = tempfile.mkdtemp(prefix="sage_variant_")
     objs, procs = [], []
     for src, extra in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
+            continue
         o = os.path.join(tmp, src.replace(".hip", ".o"))
         objs.append(o)
         cmd = [HIPCC] + COMMON + extra + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o]

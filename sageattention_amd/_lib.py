@@ -27,7 +27,14 @@ class KvLayout(ctypes.Structure):
                 ("ks_stride_h", c_int64), ("ks_stride_tile", c_int64)]
 
 
+class OpOpts(ctypes.Structure):
+    """sage_op_opts (include/sageattn_hip.h)"""
+    _fields_ = [("qk_gran", c_int), ("warpq", c_int), ("smooth_k", c_int), ("fuse_q", c_int), ("nwaves", c_int),
+                ("reserved", c_int * 3)]
+
+
 _P = ctypes.POINTER(SageTensor)
+_PO = ctypes.POINTER(OpOpts)
 _PL = ctypes.POINTER(KvLayout)
 _lib = None
 
@@ -65,6 +72,12 @@ SIGNATURES = {
     "sage_merge_attn_states_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sage_finish_lse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sage_set_tuning": (c_int, [c_int, c_int]),
+    "sage_get_tuning": (c_int, [c_int]),
+    "sage_sageattn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _PO]),
+    "sage_sageattn_pv_f16": (c_int, [_P, _P, _P, c_int, _P, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_float, _PO, c_void_p, c_size_t, c_void_p]),
+    "sage_sageattn_pv_f8": (c_int, [_P, _P, _P, c_int, _P, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_float, c_float, _PO, c_void_p, c_size_t, c_void_p]),
     "sage_k_smooth_quant": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                     c_void_p]),
     "sage_kv_prepare_fp8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -104,6 +117,8 @@ def lib():
         _lib = l
         if os.environ.get("SAGE_NWAVES"):  # tuning knob (speed only): waves per attention workgroup, 4 or 8
             l.sage_set_tuning(0, int(os.environ["SAGE_NWAVES"]))
+        if os.environ.get("SAGE_MFMA"):    # tuning knob: MFMA fragment family of the attention kernels, 16 or 32
+            l.sage_set_tuning(1, int(os.environ["SAGE_MFMA"]))
     return _lib
 
 

@@ -152,6 +152,35 @@ def _fused_attn(q, k8, ks, v, o, km, v_scale, v_mean, tensor_layout, is_causal, 
     return lse
 
 
+# One ctypes crossing and two allocations (output + workspace) per call: sage_sageattn_pv_{f16,f8} (csrc/sage_op.hip)
+# sequences the same entry points the multi-call path below uses, bit-identical.  SAGEATTN_ONE_CALL=0 selects that path.
+ONE_CALL = os.environ.get("SAGEATTN_ONE_CALL", "1") == "1"
+
+
+def _one_call(q, k, v, tensor_layout, is_causal, qk_quant_gran, warpq, sm_scale, return_lse, pv_fp8, scale_max=448.0):
+    B, Hq, M, D = L.dims(q, tensor_layout)
+    _, Hk, N, _ = L.dims(k, tensor_layout)
+    if Hq % Hk != 0:
+        raise ValueError(f"num_qo_heads ({Hq}) must be divisible by num_kv_heads ({Hk})")
+    lib = L.lib()
+    opts = L.OpOpts(_GRAN_CODE[qk_quant_gran], warpq, 1, -1 if FUSE_Q_QUANT else 0, 0)
+    if not FUSE_Q_QUANT or M > FUSE_Q_MAX_SEQ:
+        opts.fuse_q = 0
+    nbytes = lib.sage_sageattn_workspace_bytes(int(pv_fp8), B, Hq, Hk, M, N, D, int(return_lse), opts)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    o = torch.empty(q.size(), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, Hq, M), dtype=torch.float32, device=q.device) if return_lse else None
+    code, st = L.dtype_code(q.dtype), L.stream_ptr(q.device)
+    qd, kd, vd, od = (L.desc(t, tensor_layout) for t in (q, k, v, o))
+    if pv_fp8:
+        L.check(lib.sage_sageattn_pv_f8(qd, kd, vd, code, od, L.ptr(lse), B, Hq, Hk, M, N, D, int(is_causal), float(sm_scale),
+                                        float(scale_max), opts, ws.data_ptr(), nbytes, st), "sage_sageattn_pv_f8")
+    else:
+        L.check(lib.sage_sageattn_pv_f16(qd, kd, vd, code, od, L.ptr(lse), B, Hq, Hk, M, N, D, int(is_causal), float(sm_scale),
+                                         opts, ws.data_ptr(), nbytes, st), "sage_sageattn_pv_f16")
+    return o, lse
+
+
 def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smooth_k, smooth_v, return_lse, WARPQ=32):
     dtype = q.dtype
     with torch.cuda.device(q.device):  # the reference's torch.cuda.set_device(v.device) workaround, core.py:583
@@ -160,6 +189,10 @@ def _sage_fp16(q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, smoot
             sm_scale = head_dim_og ** -0.5
         _, Hq, _, _ = L.dims(q, tensor_layout)
         _, Hk, _, _ = L.dims(k, tensor_layout)
+        if ONE_CALL and smooth_k and not smooth_v and qk_quant_gran in ("per_warp", "per_thread"):
+            o, lse = _one_call(q, k, v, tensor_layout, is_causal, qk_quant_gran, WARPQ, sm_scale, return_lse, False)
+            o = o[..., :head_dim_og]
+            return (o, lse) if return_lse else o
         k8, ks, km = _prep_k(k, tensor_layout, qk_quant_gran, smooth_k)
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         vm = None
@@ -313,6 +346,10 @@ def sageattn_qk_int8_pv_fp8_cuda(
             sm_scale = head_dim_og ** -0.5
         _, Hq, _, _ = L.dims(q, tensor_layout)
         _, Hk, _, _ = L.dims(k, tensor_layout)
+        if ONE_CALL and smooth_k and not smooth_v and k.shape == v.shape:
+            o, lse = _one_call(q, k, v, tensor_layout, is_causal, qk_quant_gran, 32, sm_scale, return_lse, True)
+            o = o[..., :head_dim_og]
+            return (o, lse) if return_lse else o
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         if smooth_k and not smooth_v and k.shape == v.shape and k.dtype == v.dtype:
             # the default configuration: K and V prepared by one call (two launches instead of five up to 4096 keys)

@@ -33,7 +33,7 @@ def test_binding_covers_header(built_lib):
     from sageattention_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
     l = _lib.lib()
-    assert l.sage_abi_version() == 2
+    assert l.sage_abi_version() == 3
     assert l.sage_target_arch() == b"gfx950"
     assert b"head_dim" in l.sage_status_string(-2)
 
@@ -48,7 +48,8 @@ def test_argument_validation_without_gpu(built_lib):
     assert l.sage_quant_qk_int8(bad, 0, 1, 1, 8, 96, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -2
     assert l.sage_quant_qk_int8(bad, 7, 1, 1, 8, 64, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -1
     assert l.sage_set_tuning(0, 5) == -1 and l.sage_set_tuning(0, 0) == 0
-    assert l.sage_set_tuning(1, 1) == -1
+    assert l.sage_set_tuning(1, 1) == -1 and l.sage_set_tuning(1, 16) == 0 and l.sage_get_tuning(1) == 16
+    assert l.sage_set_tuning(1, 0) == 0 and l.sage_get_tuning(0) == 0 and l.sage_get_tuning(9) == -1
     assert l.sage_set_tuning(7, 0) == -1
 
 
@@ -82,6 +83,28 @@ def test_sequence_parallel_entry_points_validate_arguments(built_lib):
     assert l.sage_kv_prepare_fp8_workspace_bytes(2, 3, 1000, 64) >= 2 * 2 * 3 * 4 * 64 * 4
     op = (C.c_void_p * 1)(16)
     assert l.sage_merge_attn_states_multi_ex(op, op, 1, 0, 16, None, 4, 64, 0.0, None, 0.0, None) == -1   # lse multiplier must be > 0
+
+
+def test_one_call_operator_validates_arguments(built_lib):
+    """sage_sageattn_pv_{f16,f8}: workspace sizing and host-side validation, no launch."""
+    from sageattention_amd import _lib as L
+    l = L.lib()
+    t = L.SageTensor(16, 64, 64, 64)
+    ok = L.OpOpts(3, 32, 1, -1, 0)
+    n16 = l.sage_sageattn_workspace_bytes(0, 2, 4, 2, 1000, 1000, 64, 1, ok)
+    n8 = l.sage_sageattn_workspace_bytes(1, 2, 4, 2, 1000, 1000, 64, 1, ok)
+    assert n16 >= 2 * 2 * 1000 * 64 and n8 >= n16 + 2 * 2 * 64 * 1024              # int8 K; + fp8 V^T
+    big = l.sage_sageattn_workspace_bytes(0, 1, 4, 2, 8192, 8192, 128, 1, ok)       # stand-alone Q quantizer above 4096 rows
+    assert big >= 2 * 8192 * 128 + 4 * 8192 * 128 + 2 * 4 * 8192 * 4
+    assert l.sage_sageattn_workspace_bytes(0, 1, 1, 1, 64, 64, 96, 0, ok) == 0       # head_dim
+    assert l.sage_sageattn_workspace_bytes(0, 1, 1, 1, 64, 64, 64, 0, L.OpOpts(1, 32, 1, -1, 0)) == 0  # per_block: not here
+    args = (1, 2, 2, 64, 64, 64, 0, 0.125)
+    assert l.sage_sageattn_pv_f16(t, t, t, 0, t, None, *args, ok, 16, 8, None) == -1             # workspace too small
+    assert l.sage_sageattn_pv_f16(t, t, t, 0, t, None, *args, ok, None, 1 << 20, None) == -1
+    assert l.sage_sageattn_pv_f16(t, t, t, 0, t, None, *args, L.OpOpts(3, 32, 0, -1, 0), 16, 1 << 20, None) == -3  # smooth_k = 0
+    assert l.sage_sageattn_pv_f16(t, t, t, 0, t, None, *args, L.OpOpts(3, 32, 1, -1, 5), 16, 1 << 20, None) == -1  # nwaves
+    assert l.sage_sageattn_pv_f16(t, t, t, 0, t, None, 1, 3, 2, 64, 64, 64, 0, 0.125, ok, 16, 1 << 20, None) == -1  # Hq % Hk
+    assert l.sage_sageattn_pv_f8(t, t, t, 0, t, None, *args, 0.0, ok, 16, 1 << 20, None) == -1   # scale_max
 
 
 def test_product_path_has_no_oracle_import():
