@@ -76,7 +76,7 @@ const char* sage_target_arch(void);
  * makes afterwards and to no other thread's.  key SAGE_TUNE_NWAVES: waves per workgroup of the attention kernels, value
  * in {0 = the library's measured choice, 4, 8}.  The one-call operators (sage_sageattn_*) take the same choice per call
  * in their options struct instead. */
-typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0, SAGE_TUNE_MFMA = 1 /* 0 = default, 16 or 32: MFMA fragment family */ } sage_tune_key;
+typedef enum sage_tune_key { SAGE_TUNE_NWAVES = 0 } sage_tune_key;
 int sage_set_tuning(int key, int value);
 int sage_get_tuning(int key); /* the calling thread's value; -1 for an unknown key */
 
@@ -275,7 +275,7 @@ int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, int dtype, i
 /* ---- one-call operators ---------------------------------------------------------------------------------------------
  * The whole body of sageattn_qk_int8_pv_fp16_cuda (core.py:604-651) / sageattn_qk_int8_pv_fp8_cuda (core.py:786-905)
  * below their argument checks as ONE call with ONE caller-provided workspace: km = mean(k) and the INT8 K quantizer,
- * the FP8 V^T quantizer (pv_f8), the Q quantizer (folded into the attention kernel's prologue up to 4096 query rows),
+ * the FP8 V^T quantizer (pv_f8), the Q quantizer (folded into the attention kernel's prologue unless fuse_q = 0),
  * the fused attention kernel and the LSE fix of core.py:651.  It sequences the library's own entry points on `stream`
  * (sage_k_smooth_quant | sage_kv_prepare_fp8, sage_quant_qk_int8, sage_attn_{fusedq,qk_int8}_pv_*, sage_finish_lse), so
  * results are bit-identical to calling those one by one.  q, k, v, o: fp16 or bf16 (one dtype), head_dim 64 or 128 (the

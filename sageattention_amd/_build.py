@@ -16,7 +16,6 @@ SOURCES = [
     # packed f32 VALU is slower beside MFMAs; contraction off: the fused Q-quantizer prologue must round exactly like
     # K1 (sage_quant.hip) -- the tile loop spells its fmas out (__builtin_fmaf), so it is unaffected
     ("sage_attn.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
-    ("sage_attn16.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ("sage_fp8.hip", []),
     ("sage_misc.hip", []),
     ("sage_op.hip", []),

@@ -117,8 +117,6 @@ def lib():
         _lib = l
         if os.environ.get("SAGE_NWAVES"):  # tuning knob (speed only): waves per attention workgroup, 4 or 8
             l.sage_set_tuning(0, int(os.environ["SAGE_NWAVES"]))
-        if os.environ.get("SAGE_MFMA"):    # tuning knob: MFMA fragment family of the attention kernels, 16 or 32
-            l.sage_set_tuning(1, int(os.environ["SAGE_MFMA"]))
     return _lib
 
 

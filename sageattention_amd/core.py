@@ -71,14 +71,14 @@ _GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_block_cuda": L.GRAN_PER_BLOCK,
               "per_thread": L.GRAN_PER_THREAD}
 
 # Fold the Q quantizer into the attention kernel (sage_attn_fusedq_*): same bits, one launch and one pass over Q less.
-# Measured in-process (tools/ab_e2e.py): +2..4 % end to end at (4,32,2048,64), neutral at (4,32,8192,128) where the
-# per-workgroup prologue latency (one workgroup per CU) costs what the saved launch gains -- hence FUSE_Q_MAX_SEQ.
-# Default ON since round 2: the rare wrong 32-row wave seen under perturbed timing in round 1 was an LDS race in the
-# attention kernel's prologue (K buffer 0 re-filled before every wave had read it), fixed by one barrier; the fused
-# prologue only widened the window.  Evidence: profiles/r02_race_evidence.md.  SAGEATTN_FUSE_Q=0 selects the
-# stand-alone Q quantizer + kernel path (bit-identical results).
+# Re-measured end to end in round 3 (tools/fuseq_bench.py, profiles/r03_ab/fuseq_crossover.log), after the prologue learnt
+# to issue its tile copies before the Q loads: fused <= separate at every length -- 0.96-0.97 at 2K keys, 0.98-1.00 at 4K,
+# 0.993 (fp16 PV) / 0.994 (fp8 PV) at C3, 0.995 / 0.992 at C4 -- so there is no length limit any more (round 2 stopped at
+# 4096 rows, where the two paths then tied).  Default ON since round 2: the rare wrong 32-row wave seen under perturbed
+# timing in round 1 was an LDS race in the attention kernel's prologue, fixed by one barrier
+# (profiles/r02_race_evidence.md).  SAGEATTN_FUSE_Q=0 selects the stand-alone Q quantizer + kernel path (bit-identical).
 FUSE_Q_QUANT = os.environ.get("SAGEATTN_FUSE_Q", "1") == "1"
-FUSE_Q_MAX_SEQ = 4096
+FUSE_Q_MAX_SEQ = 1 << 30
 
 
 # quantizer pairings of core.py:295-299,621-624: granularity name -> (K granularity, Q granularity, rounding).
@@ -163,9 +163,7 @@ def _one_call(q, k, v, tensor_layout, is_causal, qk_quant_gran, warpq, sm_scale,
     if Hq % Hk != 0:
         raise ValueError(f"num_qo_heads ({Hq}) must be divisible by num_kv_heads ({Hk})")
     lib = L.lib()
-    opts = L.OpOpts(_GRAN_CODE[qk_quant_gran], warpq, 1, -1 if FUSE_Q_QUANT else 0, 0)
-    if not FUSE_Q_QUANT or M > FUSE_Q_MAX_SEQ:
-        opts.fuse_q = 0
+    opts = L.OpOpts(_GRAN_CODE[qk_quant_gran], warpq, 1, 1 if (FUSE_Q_QUANT and M <= FUSE_Q_MAX_SEQ) else 0, 0)
     nbytes = lib.sage_sageattn_workspace_bytes(int(pv_fp8), B, Hq, Hk, M, N, D, int(return_lse), opts)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     o = torch.empty(q.size(), dtype=q.dtype, device=q.device)

@@ -327,18 +327,7 @@ void attn_i8_kernel(const AttnParams p) {
   // every gap already holds a P.V MFMA: 4x4x4 -1.5 %, this form +0.2 ... +0.8 % -- not worth giving up the exact fp32 sums there.
   // (bf16 PV keeps the VALU sums of the unrounded p: a sum of bf16-rounded P would cost the LSE three more bits)
   constexpr bool MROW = !PV_FP8 && !V_BF16 && (D == 64 ? !abl::kValuRowSum64 : abl::kMfmaRowSum128);
-  // FP8 PV (experiment, -DSAGE_EXP_ROWSUM_BF16; head_dim 128 only -- the head_dim-64 variants have no registers left):
-  // the 32 row-sum adds of a tile become 16 v_cvt_pk_bf16_f32 + 4 v_mfma_f32_16x16x32_bf16 with the same parity-select A;
-  // l then carries the bf16 rounding of each p (2^-9 relative, zero mean), not e4m3's 2^-4
-  constexpr bool MROW8 = PV_FP8 && D == 128 && abl::kRowSumBf16F8;
   v4f l4 = {0.f, 0.f, 0.f, 0.f};
-  v8bf sel8b;
-  {
-    const __bf16 one = (((lane >> 4) & 1) == (lane & 1)) ? (__bf16)1.0f : (__bf16)0.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sel8b[e] = one;
-    if constexpr (MROW8) asm volatile("" : "+v"(sel8b));
-  }
   v8h sel8;
   {
     const _Float16 one = (((lane >> 4) & 1) == (lane & 1)) ? (_Float16)1.0f : (_Float16)0.0f;
@@ -548,7 +537,7 @@ void attn_i8_kernel(const AttnParams p) {
       m_run = m_new;
       m_thr = m_new + kLazyThr;
       l_run *= alpha;
-      if constexpr (MROW || MROW8) l4 *= alpha;
+      if constexpr (MROW) l4 *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -616,19 +605,12 @@ void attn_i8_kernel(const AttnParams p) {
     } else {
       // all 64 keys of the tile in one K=64 MFMA per d tile; P^T bytes in accumulator order j = 16*mt + reg
       v8i pb;
-      v8bf pq8;
       float psum = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
         const int mt = w >> 2, e0 = 4 * (w & 3);
         const float p0 = prob(mt, e0), p1 = prob(mt, e0 + 1), p2 = prob(mt, e0 + 2), p3 = prob(mt, e0 + 3);
-        if constexpr (MROW8) {
-          const v2bf lo = __builtin_convertvector((v2f){p0, p1}, v2bf), hi = __builtin_convertvector((v2f){p2, p3}, v2bf);
-          pq8[4 * (w & 1)] = lo[0]; pq8[4 * (w & 1) + 1] = lo[1]; pq8[4 * (w & 1) + 2] = hi[0]; pq8[4 * (w & 1) + 3] = hi[1];
-          if (w & 1) l4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel8b, pq8, l4, 0, 0, 0);
-        } else {
-          psum += p0; psum += p1; psum += p2; psum += p3;
-        }
+        psum += p0; psum += p1; psum += p2; psum += p3;
         int pk = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, 0, false);  // OCP e4m3, RNE (e4m3_rn_satfinite)
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, pk, true);
         pb[w] = pk;
@@ -831,16 +813,9 @@ void attn_i8_kernel(const AttnParams p) {
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[2], pend[3], pk, true);
         pb[w] = pk;
       };
-      v8bf pq;  // the bf16 p of two words (8 values of the lane's row): B operand of the row-sum MFMA
-      auto p_sum = [&](const int w) __attribute__((always_inline)) {  // row sum of word w
-        if constexpr (MROW8) {
-          const v2bf lo = __builtin_convertvector((v2f){pend[0], pend[1]}, v2bf), hi = __builtin_convertvector((v2f){pend[2], pend[3]}, v2bf);
-          pq[4 * (w & 1)] = lo[0]; pq[4 * (w & 1) + 1] = lo[1]; pq[4 * (w & 1) + 2] = hi[0]; pq[4 * (w & 1) + 3] = hi[1];
-          if (w & 1) l4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel8b, pq, l4, 0, 0, 0);
-        } else {
-          psum += pend[0];
-          if constexpr (!abl::kNoRowSumF8) { psum += pend[1]; psum += pend[2]; psum += pend[3]; }
-        }
+      auto p_sum = [&]() __attribute__((always_inline)) {
+        psum += pend[0];
+        if constexpr (!abl::kNoRowSumF8) { psum += pend[1]; psum += pend[2]; psum += pend[3]; }
       };
 #define SAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
       v4i kf = kf_early;
@@ -853,13 +828,13 @@ void attn_i8_kernel(const AttnParams p) {
           if (si + 1 < NS) kf = k_frag(si + 1);
           ++si;
         }
-        if (w > 0) p_sum(w - 1);
+        if (w > 0) p_sum();
         p_word(w);
         if (w == 6) vf[0] = v_frag8(0);
         if (w == 7 && DT > 1) vf[1] = v_frag8(1);
         SAGE_FENCE();
       }
-      p_sum(7);
+      p_sum();
       l_run += psum;
       // P.V beside the row max of S(j+1)
       if constexpr (NEXT == 1) { if (j + 1 >= n_plain) mask_limit(j + 1, sb); }
@@ -1008,9 +983,10 @@ void attn_i8_kernel(const AttnParams p) {
         mx_cur = swap_max(mx);
       }
     }
-#ifdef SAGE_EXP_FENCE_MAX
+    // keep the cross-lane end of the row max (a dependent chain of ~8 instructions with hazard nops) in FRONT of the
+    // tile's wait and barrier, where a wave idles anyway: hipcc sank it below the barrier in one of the two unrolled
+    // bodies, i.e. in front of the next tile's first MFMA (round 3, bit-identical: C3 +1.1 %, C3-causal +0.5 %, C2 +0.2 %)
     __builtin_amdgcn_sched_barrier(0);
-#endif
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
         dma_wait_all();  // two-slot ring: every copy of this wave has landed before the barrier publishes the tiles
@@ -1127,7 +1103,7 @@ void attn_i8_kernel(const AttnParams p) {
   }
 
   // ---- epilogue: normalise, (+ v_mean), convert, store; LSE (…sm80.cu:540-668)
-  const float l_tot = (MROW || MROW8) ? (((row_l - q0) & 16) ? l4[1] : l4[0]) : swap_sum(l_run);
+  const float l_tot = MROW ? (((row_l - q0) & 16) ? l4[1] : l4[0]) : swap_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (row_l < M_) {
     uint16_t* op = p.o + o_boff + h * p.osh + (int64_t)row_l * p.osn;
@@ -1238,10 +1214,7 @@ static bool t_ok(const sage_tensor* t, int align_elems) {
 // tuning hook (sage_set_tuning): per host thread, so a test or tool that pins the geometry for its own calls cannot change
 // the launches of another thread; 0 = the measured default below
 static thread_local int g_nwaves_override = 0;
-static thread_local int g_mfma_shape = 0;  // 16: the 16x16 MFMA kernel (sage_attn16.hip) where it covers the call
 
-bool attn16_supported(const AttnParams& p, bool pv_fp8);
-int launch_attn16(const AttnParams& p, int D, int nwaves, bool causal, bool kthread, bool v_bf16, hipStream_t st);
 
 // shared argument handling of the two attention entry points
 static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_tensor* v, bool pv_fp8, int v_dtype,
@@ -1327,7 +1300,6 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   const int keys_per_row = is_causal ? N / 2 : N;
   const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8 || keys_per_row <= 2048) ? 4 : 8);
   p.nqb = (M + nw * 32 - 1) / (nw * 32);
-  if (g_mfma_shape == 16 && attn16_supported(p, pv_fp8)) return launch_attn16(p, D, nw, is_causal, kthread, vb, st);
 #define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
   if (nw == 8) return D == 64 ? SAGE_GO(64, 8) : SAGE_GO(128, 8);
   return D == 64 ? SAGE_GO(64, 4) : SAGE_GO(128, 4);
@@ -1344,17 +1316,12 @@ extern "C" int sage_set_tuning(int key, int value) {
     g_nwaves_override = value;
     return SAGE_OK;
   }
-  if (key == SAGE_TUNE_MFMA) {
-    if (value != 0 && value != 16 && value != 32) return SAGE_ERR_INVALID_ARGUMENT;
-    g_mfma_shape = value;
-    return SAGE_OK;
-  }
+
   return SAGE_ERR_INVALID_ARGUMENT;
 }
 
 extern "C" int sage_get_tuning(int key) {
   if (key == SAGE_TUNE_NWAVES) return g_nwaves_override;
-  if (key == SAGE_TUNE_MFMA) return g_mfma_shape;
   return -1;
 }
 

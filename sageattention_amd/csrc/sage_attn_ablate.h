@@ -115,11 +115,6 @@ SAGE_ABL_FLAG(kValuRowSum64, true);
 #else
 SAGE_ABL_FLAG(kValuRowSum64, false);
 #endif
-#ifdef SAGE_EXP_ROWSUM_BF16          // FP8 PV at head_dim 128: row sums of the bf16-rounded p on v_mfma_f32_16x16x32_bf16
-SAGE_ABL_FLAG(kRowSumBf16F8, true);
-#else
-SAGE_ABL_FLAG(kRowSumBf16F8, false);
-#endif
 #undef SAGE_ABL_FLAG
 
 }  // namespace abl

@@ -1,7 +1,7 @@
 // One-call operators: everything sageattn_qk_int8_pv_fp16_cuda / sageattn_qk_int8_pv_fp8_cuda do below their argument
 // checks (core.py:604-651, 786-905) behind ONE C-ABI crossing and ONE caller-provided workspace -- K mean + INT8 K
-// (sage_k_smooth_quant / sage_kv_prepare_fp8), FP8 V, Q quantizer (folded into the attention kernel up to 4096 query
-// rows), attention, LSE fix.  Host code only: it sequences the library's own entry points on the caller's stream, so the
+// (sage_k_smooth_quant / sage_kv_prepare_fp8), FP8 V, Q quantizer (folded into the attention kernel's prologue unless
+// fuse_q = 0), attention, LSE fix.  Host code only: it sequences the library's own entry points on the caller's stream, so the
 // results are bit-identical to calling them one by one (what the Python mirror did until round 3: 3-4 crossings and 6-9
 // allocations per call, 46 us of host time against a 64 us GPU step at (4,32,1024,64)).
 #include "sage_common.h"
@@ -22,7 +22,7 @@ bool make_plan(Plan& pl, int pv_fp8, int B, int Hq, int Hk, int M, int N, int D,
   const int gran = o->qk_gran, warpq = o->warpq ? o->warpq : 32;
   if (gran != SAGE_GRAN_PER_WARP && gran != SAGE_GRAN_PER_THREAD) return false;
   if (warpq != 16 && warpq != 32) return false;
-  pl.fuse_q = o->fuse_q < 0 ? M <= 4096 : o->fuse_q != 0;
+  pl.fuse_q = o->fuse_q != 0;  // -1 (the library's choice) = fused: it is at least as fast at every length (core.py, round 3)
   pl.npad = (N + 63) / 64 * 64;
   pl.gk = (N + 63) / 64 * (gran == SAGE_GRAN_PER_THREAD ? 4 : 1);
   const int nblkq = (M + 127) / 128;

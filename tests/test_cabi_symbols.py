@@ -48,8 +48,9 @@ def test_argument_validation_without_gpu(built_lib):
     assert l.sage_quant_qk_int8(bad, 0, 1, 1, 8, 96, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -2
     assert l.sage_quant_qk_int8(bad, 7, 1, 1, 8, 64, None, bad, 16, 1, 0, 128, 128, 1.0, 0, None, 1, None, None) == -1
     assert l.sage_set_tuning(0, 5) == -1 and l.sage_set_tuning(0, 0) == 0
-    assert l.sage_set_tuning(1, 1) == -1 and l.sage_set_tuning(1, 16) == 0 and l.sage_get_tuning(1) == 16
-    assert l.sage_set_tuning(1, 0) == 0 and l.sage_get_tuning(0) == 0 and l.sage_get_tuning(9) == -1
+    assert l.sage_set_tuning(1, 1) == -1
+    assert l.sage_set_tuning(0, 8) == 0 and l.sage_get_tuning(0) == 8 and l.sage_set_tuning(0, 0) == 0
+    assert l.sage_get_tuning(0) == 0 and l.sage_get_tuning(9) == -1
     assert l.sage_set_tuning(7, 0) == -1
 
 
@@ -94,7 +95,7 @@ def test_one_call_operator_validates_arguments(built_lib):
     n16 = l.sage_sageattn_workspace_bytes(0, 2, 4, 2, 1000, 1000, 64, 1, ok)
     n8 = l.sage_sageattn_workspace_bytes(1, 2, 4, 2, 1000, 1000, 64, 1, ok)
     assert n16 >= 2 * 2 * 1000 * 64 and n8 >= n16 + 2 * 2 * 64 * 1024              # int8 K; + fp8 V^T
-    big = l.sage_sageattn_workspace_bytes(0, 1, 4, 2, 8192, 8192, 128, 1, ok)       # stand-alone Q quantizer above 4096 rows
+    big = l.sage_sageattn_workspace_bytes(0, 1, 4, 2, 8192, 8192, 128, 1, L.OpOpts(3, 32, 1, 0, 0))  # fuse_q = 0: stand-alone Q quantizer
     assert big >= 2 * 8192 * 128 + 4 * 8192 * 128 + 2 * 4 * 8192 * 4
     assert l.sage_sageattn_workspace_bytes(0, 1, 1, 1, 64, 64, 96, 0, ok) == 0       # head_dim
     assert l.sage_sageattn_workspace_bytes(0, 1, 1, 1, 64, 64, 64, 0, L.OpOpts(1, 32, 1, -1, 0)) == 0  # per_block: not here

@@ -789,7 +789,8 @@ def test_k_smooth_quant_is_bit_identical_to_mean_plus_quantizer(sa, layout, dt):
     from sageattention_amd import _lib as L
     from sageattention_amd.quant import _quant, k_mean, k_smooth_quant
     for i, (B, H, N, D) in enumerate([(1, 1, 1, 64), (2, 3, 63, 128), (1, 2, 257, 64), (2, 4, 1000, 128), (1, 5, 4096, 64),
-                                      (1, 2, 4097, 128), (2, 8, 8192, 128)]):
+                                      (1, 2, 4097, 128), (2, 8, 8192, 128), (4, 32, 1024, 64), (3, 32, 2048, 64),
+                                      (4, 24, 1000, 128), (2, 48, 1, 64), (2, 50, 1537, 64), (4, 32, 1024, 128), (3, 40, 65, 128)]):
         g = torch.Generator(device="cuda").manual_seed(300 + i)
         shape = (B, H, N, D) if layout == "HND" else (B, N, H, D)
         k = (torch.randn(shape, device="cuda", generator=g) * 2 + torch.randn((1, 1, 1, D), device="cuda", generator=g) * 3).to(dt)

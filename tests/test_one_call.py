@@ -11,14 +11,15 @@ CASES = [  # B, Hq, Hk, M, N, D, layout, dtype, causal, gran
     (2, 4, 4, 256, 256, 64, "HND", torch.float16, False, "per_thread"),
     (1, 8, 2, 300, 300, 128, "NHD", torch.bfloat16, True, "per_warp"),
     (1, 2, 2, 100, 1000, 128, "HND", torch.float16, False, "per_thread"),   # M != N
-    (1, 2, 2, 4200, 4200, 64, "HND", torch.float16, True, "per_thread"),    # above FUSE_Q_MAX_SEQ: stand-alone Q quantizer
+    (1, 2, 2, 4200, 4200, 64, "HND", torch.float16, True, "per_thread"),
     (1, 2, 1, 4160, 520, 128, "NHD", torch.bfloat16, False, "per_warp"),
 ]
 
 
+@pytest.mark.parametrize("fused_q", [True, False], ids=["fusedq", "separate_q"])
 @pytest.mark.parametrize("pv", ["fp16", "fp8"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x).replace("torch.", "") for x in c))
-def test_one_call_is_bit_identical_to_the_multi_call_path(case, pv):
+def test_one_call_is_bit_identical_to_the_multi_call_path(case, pv, fused_q):
     import sageattention_amd as sa
     from sageattention_amd import core
     B, Hq, Hk, M, N, D, layout, dt, causal, gran = case
@@ -30,7 +31,8 @@ def test_one_call_is_bit_identical_to_the_multi_call_path(case, pv):
     k = (torch.randn(shp(Hk, N), device="cuda") + 1.0).to(dt)
     v = torch.randn(shp(Hk, N), dtype=dt, device="cuda")
     fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
-    keep = core.ONE_CALL
+    keep, keep_f = core.ONE_CALL, core.FUSE_Q_QUANT
+    core.FUSE_Q_QUANT = fused_q   # False: the stand-alone Q quantizer + finish-LSE legs of both paths
     try:
         res = {}
         for one in (True, False):
@@ -39,7 +41,7 @@ def test_one_call_is_bit_identical_to_the_multi_call_path(case, pv):
             res[(one, "nolse")] = fn(q, k, v, tensor_layout=layout, is_causal=causal, qk_quant_gran=gran)
         torch.cuda.synchronize()
     finally:
-        core.ONE_CALL = keep
+        core.ONE_CALL, core.FUSE_Q_QUANT = keep, keep_f
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     assert torch.equal(res[(True, "nolse")], res[(False, "nolse")]) and torch.equal(res[True][0], res[(True, "nolse")])
     assert torch.isfinite(res[True][0].float()).all() and torch.isfinite(res[True][1]).all()
