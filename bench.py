@@ -147,6 +147,7 @@ def main():
     if wl == "ring" and use_dist:
         from sageattention_amd import ring
         n_local = N // world
+        torch.manual_seed(1000 + rank)   # every rank its own shard (identical shards would hide a mixed-up exchange)
         q = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
         k = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
         v = torch.randn(B, H, n_local, D, dtype=torch.float16, device=dev)
@@ -235,6 +236,10 @@ def main():
                     traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
             out["roofline"] = {"bound": "mfma", "achieved": round(k_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(k_tflops / peak, 4), "traffic": traffic,
+                               # `traffic` is NOT measured by this run (PMC counters need rocprofv3 around the process): it is
+                               # read from the committed counter passes of this kernel on this workload, named here
+                               "traffic_from": (os.path.relpath(cands[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                "passes, tools/profile_round.sh)") if cands else None,
                                "kernel": f"attn_i8_kernel<D={D}, pv={variant}>",
                                "kernel_ms": round(k_ms, 4), "flops_per_launch": total_flops,
                                # context, measured with tools/mfma_power.hip on random operands:
@@ -271,12 +276,33 @@ def main():
             out["cpu_baseline"] = port
             out["cpu_sdpa"] = sdpa
     if use_dist and world > 1 and wl == "ring":
-        # context for the driver's scaling table (N = 1 runs C3, a different workload): the SAME problem on ONE GPU through the
-        # single-GPU operator, a few launches on rank 0 after the timed region; the other ranks wait at the barrier
+        # context for the driver's scaling table (N = 1 runs C3, a different workload): the SAME problem -- the very tensors
+        # of the timed run, gathered on rank 0 -- on ONE GPU through the single-GPU operator, a few launches after the timed
+        # region (the other ranks wait at the barrier).  The first real multi-GPU run thereby VALIDATES itself: rank 0's rows
+        # of the sequence-parallel result are compared with the same rows of the one-GPU result.
+        o_loc = step()
+        o_loc = (o_loc[0] if isinstance(o_loc, tuple) else o_loc).contiguous()
+        full = []
+        for t in (q, k, v):
+            flat = torch.empty(world * t.numel(), dtype=t.dtype, device=dev)
+            dist.all_gather_into_tensor(flat, t.contiguous().reshape(-1))
+            full.append(flat.view((world,) + tuple(t.shape)))
         if rank == 0:
             try:
-                qa, ka, va = (torch.randn(B, H, N, D, dtype=torch.float16, device=dev) for _ in range(3))
+                zig = causal and args.sp == "ring" and args.causal_layout == "zigzag"
+                if zig:
+                    qa, ka, va = (ring.zigzag_merge(list(t.unbind(0))) for t in full)
+                else:  # contiguous shards (ulysses shards the sequence the same way)
+                    qa, ka, va = (torch.cat(list(t.unbind(0)), dim=2) for t in full)
+                del full
                 entry1 = sa.sageattn_qk_int8_pv_fp16_cuda if variant == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+                o_one = entry1(qa, ka, va, is_causal=causal, qk_quant_gran=args.gran)
+                mine = ring.zigzag_split(o_one, world, 0) if zig else o_one[:, :, :n_local]
+                diff = float((o_loc.float() - mine.float()).abs().max())
+                # same quantized operands up to the smoothing statistics' reduction order; different key order and merge
+                tol = (0.06 if causal else 0.03) if variant == "fp8" else 4e-3
+                out["validation"] = {"max_abs_diff_vs_one_gpu": round(diff, 6), "rows": int(mine.shape[2]), "tolerance": tol,
+                                     "ok": bool(diff < tol)}
                 one_ms = time_events(lambda: entry1(qa, ka, va, is_causal=causal, qk_quant_gran=args.gran), 3, 1)
                 one_tf = total_flops / (one_ms * 1e-3) / 1e12
                 out["one_gpu_same_problem"] = {"ms": round(one_ms, 4), "tflops": round(one_tf, 2),

@@ -145,6 +145,9 @@ int sage_quant_v_fp8(const sage_tensor* v, int dtype, int B, int H, int N, int D
  *   q8 [B,Hq,M,D] int8, k8 [B,Hk,N,D] int8, v [B,Hk,N,D] fp16 or bf16 (v_dtype), o [B,Hq,M,D] fp16/bf16 (o_dtype).
  *   A bf16 v is used as it is: P is rounded to bf16 and P.V runs on the bf16 MFMA with fp32 accumulation (the reference
  *   converts v to fp16 first, core.py:633 `v.to(float16)`; a caller who wants exactly that passes the converted tensor).
+ *   Precision note: v_dtype = BF16 selects the bf16 P (8 significant bits) whatever o_dtype is -- with o_dtype = F16 the
+ *   result carries 3 bits less in P than the fp16-V call (|do| <= 2^-8 * sum(p |v|) / l per element); bf16 outputs round
+ *   at that size anyway.
  *   q_scale / k_scale: fp32 [B,Hq,Gq] / [B,Hk,Gk] with the shapes sage_quant_qk_int8 produces for
  *   (gran, blkq, warpq, blkk=64, warpk=64)  (…sm80.cu:796-805).
  *   sm_scale: logits are multiplied by sm_scale*log2(e) inside the kernel (…sm80.cu:92); must be

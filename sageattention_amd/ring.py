@@ -39,7 +39,8 @@ each other:
            consumes the peers' shards in ring order as they land: all 7 links carry traffic concurrently and the
            exchange is paid once instead of P-1 times.  Costs P-1 receive buffers (C5: 7 x ~100 MB, trivial in 288 GB).
 At C5 (n = 8192 rows per rank, D = 128, 32 heads) one block is ~1.1 TFLOP (~0.85 ms) while a ring step moves ~100 MB
-over a single link (>1.3 ms): the ring would be communication bound, the direct schedule is not.  Default: "direct".
+over a single link (>1.3 ms): the ring would be communication bound, the all-link schedules are not.  Default: "gather"
+(``schedule="direct"`` is the documented opt-out: per-shard smoothing, results bit-identical to "ring").
 """
 import ctypes
 from typing import Any, Optional
@@ -329,27 +330,54 @@ def _all_gather_stats(st, world, group):
     return flat.view((world,) + tuple(st.shape))
 
 
-def _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer):
+def _exchange_batches(world, nbatch):
+    """Slot offsets p = 1 .. world-1 cut into at most ``nbatch`` contiguous groups, nearest ranks first: [(p_lo, p_hi), ...)
+    with p_hi exclusive.  The cut depends on ``world`` only, so the send a rank posts in batch i is the receive of its peer
+    in the SAME batch i (RCCL matches sends and receives of a pair in issue order)."""
+    n = world - 1
+    nbatch = max(1, min(nbatch, n))
+    edges = [1 + (n * i + nbatch - 1) // nbatch for i in range(nbatch + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(nbatch) if edges[i + 1] > edges[i]]
+
+
+GATHER_BATCHES = 3   # exchange batches of the gather schedule (see _gather_schedule)
+
+
+def _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer, nbatch=None, delay=None):
     """schedule="gather" (module docstring).  Slot p of a rank's exchange buffer holds the shard of rank (rank - p) mod P:
-    its own shard first, then the ranks before it -- exactly the shards a causal rank needs, contiguously."""
+    its own shard first, then the ranks before it -- exactly the shards a causal rank needs, contiguously.
+
+    The exchange is posted in ``nbatch`` batches of neighbouring slots (one RCCL group each, all posted up front), and the
+    rank attends the slots of a batch as soon as THAT batch has landed: own shard | batch 1 | batch 2 | ... each with one
+    launch of the attention kernel over a contiguous run of slots, one multi-way merge at the end.  Round 2 waited for every
+    request and then issued one launch over all remote slots, so only the local 1/P of the work overlapped the exchange
+    and the step ended one whole remote launch after the slowest peer; now everything but the last batch's launch does.
+    The launches and the merge order are fixed by (world, nbatch), never by arrival order: results are bit-identical
+    whatever the timing (tests/test_ring_gloo.py delays one rank).  ``delay``: test hook, called before the sends are posted."""
     all_stats = _all_gather_stats(be.stats(k, v), world, group)
     S = be.setup(all_stats, world, k, v)
     G = S.buf
     qstate = be.prepare_q(q, sm_scale, return_lse)
     nremote = (rank if is_causal else world - 1) if world > 1 else 0           # slots 1 .. nremote are used
-    ops = []
-    for p_ in range(1, world):
-        dst, src = (rank + p_) % world, (rank - p_) % world
-        if not (is_causal and dst < rank):      # rank dst attends our shard (its slot p_)
-            ops.append(dist.P2POp(dist.isend, G[0], peer(dst), group))
-        if p_ <= nremote:
-            ops.append(dist.P2POp(dist.irecv, G[p_], peer(src), group))
-    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if delay is not None:
+        delay()
+    batches = _exchange_batches(world, GATHER_BATCHES if nbatch is None else nbatch) if world > 1 else []
+    pending = []
+    for lo, hi in batches:
+        ops = []
+        for p_ in range(lo, hi):
+            dst, src = (rank + p_) % world, (rank - p_) % world
+            if not (is_causal and dst < rank):      # rank dst attends our shard (its slot p_)
+                ops.append(dist.P2POp(dist.isend, G[0], peer(dst), group))
+            if p_ <= nremote:
+                ops.append(dist.P2POp(dist.irecv, G[p_], peer(src), group))
+        pending.append((lo, min(hi, nremote + 1), dist.batch_isend_irecv(ops) if ops else []))
     parts = [be.attend(qstate, S, 0, 1, is_causal)]       # own shard, while the exchange is in flight
-    for r in reqs:
-        r.wait()
-    if nremote:
-        parts.append(be.attend(qstate, S, 1, nremote, False))  # every remote shard in one launch
+    for lo, hi, reqs in pending:
+        for r in reqs:
+            r.wait()
+        if hi > lo:
+            parts.append(be.attend(qstate, S, lo, hi - lo, False))  # the remote shards of this batch in one launch
     return be.merge(parts, qstate, return_lse)
 
 
@@ -433,7 +461,8 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
     """SageAttention over a sequence sharded across the ranks of ``group``.  Equal shard lengths; rank r holds rows
     [r*n, (r+1)*n) of q, k, v (``causal_layout="contiguous"``) or the zigzag rows ``zigzag_split(x, P, r)``
     (``"zigzag"``, balances causal work; chunk length n/2 must be a multiple of 128).  Same tensor conventions as
-    ``sageattn``; returns this rank's output rows (and their LSE) in the same local order."""
+    ``sageattn``; returns this rank's output rows (and their LSE) in the same local order.
+    ``gather_batches`` (keyword, schedule "gather"): number of exchange batches (default GATHER_BATCHES)."""
     if tensor_layout == "NHD":
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     elif tensor_layout != "HND":
@@ -445,6 +474,10 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
     zigzag = is_causal and causal_layout == "zigzag"
     if zigzag and (q.size(2) % 256 or k.size(2) != q.size(2)):
         raise ValueError("zigzag layout needs equal q/kv shard lengths that are a multiple of 256 rows")
+    if is_causal and q.size(2) != k.size(2):
+        # every schedule launches the rank's own shard causal with M = q rows, N = k rows: the diagonal only lines up
+        # when the two are equal (the reference asserts the same for its causal kernels, attn_qk_int8_per_block_causal.py:150)
+        raise ValueError("causal sequence-parallel attention needs equal q and kv shard lengths")
     D = q.size(-1)
     if D not in (64, 128):
         raise ValueError(f"ring_sageattn supports head_dim 64 or 128, got {D}")
@@ -469,7 +502,8 @@ def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layo
             if zigzag:
                 o, lse = _gather_zigzag(be, q, k, v, sm_scale, return_lse, group, world, rank, peer)
             else:
-                o, lse = _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer)
+                o, lse = _gather_schedule(be, q, k, v, is_causal, sm_scale, return_lse, group, world, rank, peer,
+                                          nbatch=kwargs.get("gather_batches"), delay=kwargs.get("_gather_delay"))
             if tensor_layout == "NHD":
                 o = o.transpose(1, 2)
             return (o, lse) if return_lse else o

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_DIR, calc_diff
+from conftest import GOLDEN_DIR, LSE2_TOL_FP32_P, LSE2_TOL_ROUNDED_P, calc_diff
 
 
 def _load():
@@ -64,8 +64,8 @@ def test_masked_hip_vs_reference(kind):
         assert (o.cpu().float() - ref)[:, :, sel].abs().max() < 4e-3
         assert calc_diff(o.cpu().float()[:, :, sel], ref[:, :, sel]) < 1e-5
         # head_dim 64: l is summed from the fp16-rounded P (MFMA row sums, as the reference's CUDA kernel), the
-        # reference Triton kernel sums the fp32 p: up to 2^-11 relative in l for rows that keep few keys
-        assert (lse.cpu() - rl)[:, :, sel].abs().max() < 1.5e-3
+        # reference Triton kernel sums the fp32 p: one rounding instance, bound derived in conftest
+        assert (lse.cpu() - rl)[:, :, sel].abs().max() < LSE2_TOL_ROUNDED_P
         # the same call with V given as bf16 (multiplied as bf16, P rounded to bf16): the fixture's fp16 V loses 3 bits on
         # the way, P another 3 -- within 3e-2 of the reference output; the LSE does not depend on V
         o_b = torch.empty_like(o)
@@ -79,7 +79,7 @@ def test_masked_hip_vs_reference(kind):
         torch.cuda.synchronize()
         L.lib().sage_set_tuning(0, 0)
         assert (o_b.cpu().float() - ref)[:, :, sel].abs().max() < 3e-2
-        assert (lse_b.cpu() - rl)[:, :, sel].abs().max() < 1.5e-3
+        assert (lse_b.cpu() - rl)[:, :, sel].abs().max() < LSE2_TOL_FP32_P   # bf16 P: fp32 sums of the unrounded p
 
 
 @pytest.mark.gpu
@@ -187,7 +187,7 @@ def test_masked_per_thread_hip_vs_reference(name, kind):
             assert (got - ref)[sel].abs().max() < tol, (name, kind, nw, v_el)
             if dt == torch.float16:
                 assert calc_diff(got[sel], ref[sel]) < 1e-5
-            assert (lse.cpu() - rl)[sel].abs().max() < (1.5e-3 if D == 64 else 5e-4)
+            assert (lse.cpu() - rl)[sel].abs().max() < (LSE2_TOL_ROUNDED_P if (D == 64 and v_el == 0) else LSE2_TOL_FP32_P)
 
 
 @pytest.mark.gpu

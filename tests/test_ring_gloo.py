@@ -158,9 +158,16 @@ def _gather_worker(rank, world, port, cfg, out_dir):
         ql, kl, vl = (t[:, :, rank * n:(rank + 1) * n] for t in (q, k, v))
     if layout == "NHD":
         ql, kl, vl = (t.transpose(1, 2).contiguous() for t in (ql, kl, vl))
+    extra = cfg[10] if len(cfg) > 10 else {}
+    kw = {}
+    if "batches" in extra:
+        kw["gather_batches"] = extra["batches"]
+    if extra.get("late_rank") == rank:   # this rank posts its sends late: every peer's first batch lands late
+        import time
+        kw["_gather_delay"] = lambda: time.sleep(1.5)
     o, lse = ring_sageattn(ql, kl, vl, tensor_layout=layout, is_causal=causal, return_lse=True, pv=pv, qk_quant_gran=gran,
                            backend=OracleGatherBackend(pv=pv, qk_quant_gran=gran), schedule="gather",
-                           causal_layout="zigzag" if zig else "contiguous")
+                           causal_layout="zigzag" if zig else "contiguous", **kw)
     if layout == "NHD":
         o = o.transpose(1, 2)
     torch.save({"o": o.contiguous(), "lse": lse}, os.path.join(out_dir, f"r{rank}.pt"))
@@ -197,6 +204,7 @@ def test_gather_schedule_matches_the_unsharded_operator(tmp_path, world, causal,
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from ring_cpu_backend import OracleGatherBackend
+    from sageattention_amd.ring import GATHER_BATCHES, _exchange_batches
     n = N // world
     bes = [OracleGatherBackend(pv=pv, qk_quant_gran=gran) for _ in range(world)]
     shards = [(k[:, :, r * n:(r + 1) * n], v[:, :, r * n:(r + 1) * n]) for r in range(world)]
@@ -208,8 +216,10 @@ def test_gather_schedule_matches_the_unsharded_operator(tmp_path, world, causal,
         qs = bes[r].prepare_q(q[:, :, r * n:(r + 1) * n], D ** -0.5, True)
         parts = [bes[r].attend(qs, Gs[r], 0, 1, causal)]
         nrem = (r if causal else world - 1)
-        if nrem:
-            parts.append(bes[r].attend(qs, Gs[r], 1, nrem, False))
+        for lo, hi in _exchange_batches(world, GATHER_BATCHES):   # one launch per exchange batch, in slot order
+            hi = min(hi, nrem + 1)
+            if hi > lo:
+                parts.append(bes[r].attend(qs, Gs[r], lo, hi - lo, False))
         so, sl = bes[r].merge(parts, qs, True)
         assert torch.equal(so, outs[r]["o"]), f"rank {r} output differs from the serial replay"
         assert torch.equal(sl, outs[r]["lse"])
@@ -237,3 +247,34 @@ def test_gather_schedule_zigzag_causal(tmp_path, world, pv, layout, gran):
     oo, ol = O.sageattn_oracle(q, k, v, is_causal=True, qk_quant_gran=gran, pv=pv, return_lse=True)
     assert (o - oo.float()).abs().max() < (2e-3 if pv == "fp16" else 6e-2)   # fp8: rows with a handful of keys, one e4m3 step
     assert (lse - ol).abs().max() < 1e-3
+
+
+def test_exchange_batches_partition_the_slots():
+    from sageattention_amd.ring import _exchange_batches
+    for world in range(2, 10):
+        for nb in (1, 2, 3, 4, 9):
+            b = _exchange_batches(world, nb)
+            assert 1 <= len(b) <= min(nb, world - 1)
+            assert b[0][0] == 1 and b[-1][1] == world and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_gather_schedule_is_independent_of_arrival_order(tmp_path, causal):
+    """The exchange of the gather schedule is posted in batches and a rank attends each batch as it lands.  Which launches
+    run and the order of the merge are fixed by (world, batches), so one deliberately LATE rank (it posts its sends 1.5 s
+    after the others) must not change a single bit of any rank's result; a different number of batches changes only the
+    grouping of the launches and of the multi-way merge (<= 2 output ulps, LSE <= 1e-4: fp32 sums in another association)."""
+    world = 4
+    res = {}
+    for tag, extra in (("on_time", {"batches": 3}), ("late", {"batches": 3, "late_rank": 2}), ("one_batch", {"batches": 1})):
+        d = tmp_path / tag
+        d.mkdir()
+        cfg = (1, 4, 2, 128 * world, 64, causal, "fp16", "HND", "per_thread", "contiguous", extra)
+        mp.spawn(_gather_worker, args=(world, _free_port(), cfg, str(d)), nprocs=world, join=True)
+        res[tag] = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(world)]
+    for r in range(world):
+        assert torch.equal(res["late"][r]["o"], res["on_time"][r]["o"]) and torch.equal(res["late"][r]["lse"], res["on_time"][r]["lse"])
+        a, b = res["one_batch"][r]["o"].float(), res["on_time"][r]["o"].float()
+        assert ((a - b).abs() <= 2 * 2.0 ** -10 * b.abs().clamp(min=0.25)).all()
+        assert (res["one_batch"][r]["lse"] - res["on_time"][r]["lse"]).abs().max() < 1e-4
