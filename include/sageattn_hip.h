@@ -257,9 +257,8 @@ int sage_finish_lse(const float* lse2, const float* corr, float sm_scale, float*
                     int64_t n, sage_stream_t stream);
 
 /* ---- K smoothing + quantization in one call ------------------------------------------
- * = sage_k_mean + sage_quant_qk_int8(is_key = 1, mean = km, blk 64, mult 1), bit-identical, with the final reduction of
- * the mean folded into the quantizer for sequences of at most 4096 rows (one launch less where launches are what the
- * pre-pass costs).  gran: SAGE_GRAN_PER_BLOCK or SAGE_GRAN_PER_THREAD; km: [B,H,D] out (dtype of k); workspace as
+ * = sage_k_mean + sage_quant_qk_int8(is_key = 1, mean = km, blk 64, mult 1), bit-identical, in TWO launches at every length:
+ * the sequence is cut into at most 16 chunks whose column sums the quantizer finishes itself (one launch less than the pair).  gran: SAGE_GRAN_PER_BLOCK or SAGE_GRAN_PER_THREAD; km: [B,H,D] out (dtype of k); workspace as
  * sage_k_mean.  Replaces `k.mean` (core.py:612) + quant_per_block_int8_fuse_sub_mean_cuda (fused.cu:594-682) / the K half
  * of per_thread_int8 (triton/quant_per_thread.py:48-102,162-163). */
 int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H, int N, int D, const sage_tensor* out,
@@ -267,9 +266,8 @@ int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H, int N, in
 
 /* The whole K/V side of the FP8-PV operator's pre-pass as ONE call: km + INT8 K (as sage_k_smooth_quant) and the FP8 V^T
  * with its per-channel scale (as sage_quant_v_fp8 with v_mean = NULL, i.e. smooth_v = False), k and v of equal shape
- * [B,H,N,D].  Up to 4096 rows it runs as two launches (K and V column statistics per chunk; both quantizers, each finishing
- * its own statistics) instead of five; longer sequences run the two separate entry points.  Results are bit-identical to
- * those either way.  Replaces core.py:612 + :621-624 (K half) + per_channel_fp8 (quant.py:225-322, fused.cu:262-427). */
+ * [B,H,N,D].  At every length it runs as two launches (K and V column statistics per chunk; both quantizers, each finishing
+ * its own statistics) instead of five.  Results are bit-identical to the two separate entry points.  Replaces core.py:612 + :621-624 (K half) + per_channel_fp8 (quant.py:225-322, fused.cu:262-427). */
 size_t sage_kv_prepare_fp8_workspace_bytes(int B, int H, int N, int D);
 int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, int dtype, int B, int H, int N, int D,
                         const sage_tensor* k_int8, float* k_scale, void* km, int gran, int rounding,

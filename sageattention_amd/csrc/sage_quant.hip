@@ -14,7 +14,15 @@ namespace sage {
 // ------------------------------------------------------------------------------------------------
 // K0: k_mean, deterministic two-pass reduction
 // ------------------------------------------------------------------------------------------------
-constexpr int KMEAN_ROWS = 256;  // rows per workgroup in pass 1
+constexpr int KMEAN_ROWS = 256;  // granule of the pass-1 chunks (rows)
+// Rows per pass-1 chunk: a multiple of KMEAN_ROWS chosen so that a sequence never has more than 16 chunks -- the quantizers
+// then ALWAYS finish the statistics themselves (16 partial rows per head out of L2), i.e. the K pre-pass is two launches
+// and the FP8 operator's K + V pre-pass is two launches at every length (round 3; up to 4096 rows the chunks are the 256
+// rows of rounds 1-2, so nothing changes there bit for bit; beyond, the partial sums are taken over longer chunks).
+__host__ __device__ __forceinline__ int kmean_chunk_rows(int N) {
+  const int c256 = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
+  return KMEAN_ROWS * ((c256 + 15) / 16 > 0 ? (c256 + 15) / 16 : 1);
+}
 
 // chunk s (KMEAN_ROWS rows) of head (b, h) of H: column sums -> part[b][h][s][D]; `red`: 256/(D/8) x (D+1) floats of LDS
 template <int D, bool BF16>
@@ -26,9 +34,10 @@ __device__ __forceinline__ void k_mean_partial_body(const uint16_t* __restrict__
   const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
   const uint16_t* base = k + b * sb + h * sh + tc * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int r0 = s * KMEAN_ROWS;
+  const int rows = kmean_chunk_rows(N);
+  const int r0 = s * rows;
 #pragma unroll 4
-  for (int i = 0; i < KMEAN_ROWS / RPP; ++i) {
+  for (int i = 0; i < rows / RPP; ++i) {
     const int row = r0 + i * RPP + tr;
     if (row < N) {
       const uint4 u = *reinterpret_cast<const uint4*>(base + (int64_t)row * sn);
@@ -295,9 +304,10 @@ __device__ __forceinline__ void v_amax_partial_body(const uint16_t* __restrict__
   const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
   const uint16_t* base = v + b * sb + h * sh + tc * 8;
   float am[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rows in [N, ceil16(N)) count as zeros (fused.cu:335): the same as starting at 0
+  const int rows = kmean_chunk_rows(N);
 #pragma unroll 4
-  for (int i = 0; i < VQ_ROWS / RPP; ++i) {
-    const int row = s * VQ_ROWS + i * RPP + tr;
+  for (int i = 0; i < rows / RPP; ++i) {
+    const int row = s * rows + i * RPP + tr;
     if (row < N) {
       float f[8];
       unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
@@ -408,7 +418,7 @@ extern "C" int sage_k_mean(const sage_tensor* k, int dtype, int B, int H, int N,
   if (!tensor_ok(k, 8) || !km || !workspace || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
-  const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
+  const int rows = kmean_chunk_rows(N), S = (N + rows - 1) / rows;
   hipStream_t st = (hipStream_t)stream;
   launch_begin();
   dim3 grid(S, H, B);
@@ -519,18 +529,13 @@ extern "C" int sage_quant_k_int8_kvtiles(const sage_tensor* k, int dtype, int B,
 }
 
 // K smoothing + quantization as one call: km = mean over the sequence (sage_k_mean) and the INT8 quantization of k - km
-// (sage_quant_qk_int8 with is_key = 1, blk 64).  Two launches when the sequence has at most 16 chunks of 256 rows (the
-// quantizer finishes the mean itself), three otherwise; bit-identical to the two separate entry points.
+// (sage_quant_qk_int8 with is_key = 1, blk 64).  Two launches at every length: the sequence is cut into at most 16 chunks
+// (kmean_chunk_rows) and the quantizer finishes the mean itself; bit-identical to the two separate entry points.
 extern "C" int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H, int N, int D, const sage_tensor* out,
                                    float* scale, void* km, int gran, int rounding, void* workspace, sage_stream_t stream) {
   if (!km || !workspace) return SAGE_ERR_INVALID_ARGUMENT;
   if (gran != SAGE_GRAN_PER_BLOCK && gran != SAGE_GRAN_PER_THREAD) return SAGE_ERR_INVALID_ARGUMENT;
-  const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
-  if (S > 16) {
-    const int st = sage_k_mean(k, dtype, B, H, N, D, km, workspace, stream);
-    if (st != SAGE_OK) return st;
-    return quant_impl(k, dtype, B, H, N, D, km, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr);
-  }
+  const int rows = kmean_chunk_rows(N), S = (N + rows - 1) / rows;   // <= 16 chunks at every length
   if (!tensor_ok(k, 8) || B <= 0 || H <= 0 || N <= 0) return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
@@ -566,13 +571,7 @@ extern "C" int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, i
     return SAGE_ERR_INVALID_ARGUMENT;
   if (D != 64 && D != 128) return SAGE_ERR_UNSUPPORTED_HEAD_DIM;
   if (dtype != SAGE_F16 && dtype != SAGE_BF16) return SAGE_ERR_INVALID_ARGUMENT;
-  const int S = (N + KMEAN_ROWS - 1) / KMEAN_ROWS;
-  if (S > 16) {  // long sequences: the launches are a small share, and the quantizers finish their statistics separately
-    const int st = sage_k_smooth_quant(k, dtype, B, H, N, D, k_int8, k_scale, km, gran, rounding, workspace, stream);
-    if (st != SAGE_OK) return st;
-    return sage_quant_v_fp8(v, dtype, B, H, N, D, v_fp8, v_scale, nullptr, scale_max,
-                            (char*)workspace + sage_k_mean_workspace_bytes(B, H, N, D), stream);
-  }
+  const int rows = kmean_chunk_rows(N), S = (N + rows - 1) / rows;   // <= 16 chunks at every length
   float* kpart = (float*)workspace;
   float* vpart = kpart + (size_t)B * H * S * D;
   QuantParams p;
