@@ -1297,8 +1297,11 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   // workgroups per CU overlap them better).  Re-measured at the end of round 2 (the prologue now issues its tile copies
   // first): 4-wave +10 % at 1024 keys, +7 % at 1536, +6 % at 2048, 0 % at 3072-4096, -2 % from 6144; causal (a row attends
   // half the keys on average) +21 % at 2048, +13 % at 4096, 0 % at 8192, -1 % at 16384 -> 4 waves up to 2048 keys per row.
+  // Round 3, end to end with the Q quantizer in the prologue (tools/nw_e2e.py, profiles/r03_ab/geometry_end_to_end.log): the
+  // heavier prologue moves the crossover out -- 4-wave 0.959x the 8-wave time at 2048 keys, 0.979x at 3072, 0.998x at 4096,
+  // 1.02x from 6144; causal 0.993x at 8192 (4096 keys per row on average) -> 4 waves up to 3072 keys per row.
   const int keys_per_row = is_causal ? N / 2 : N;
-  const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8 || keys_per_row <= 2048) ? 4 : 8);
+  const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8 || keys_per_row <= 3072) ? 4 : 8);
   p.nqb = (M + nw * 32 - 1) / (nw * 32);
 #define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
   if (nw == 8) return D == 64 ? SAGE_GO(64, 8) : SAGE_GO(128, 8);

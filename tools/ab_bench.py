@@ -54,7 +54,6 @@ for spec in a.libs:
 st = torch.cuda.current_stream().cuda_stream
 def run(l, tune):
     l.sage_set_tuning(0, tune[0])
-    if tune[1]: l.sage_set_tuning(1, tune[1])   # MFMA fragment family: only libraries built from the round-3 commit that had both
     if a.pv == "fp8":
         r = l.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, L.desc(o, "HND"), EL, qs.data_ptr(),
                                       ks.data_ptr(), vs.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,
