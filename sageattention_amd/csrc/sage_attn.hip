@@ -144,7 +144,8 @@ void attn_i8_kernel(const AttnParams p) {
       }
     };
     float amax = 0.f, dot = 0.f;
-    const uint16_t* kmp = p.km ? p.km + ((int64_t)b * p.Hk + hk) * D + 16 * hh : nullptr;
+    // (the row dot q . k_mean is the LSE correction: only computed when the caller asked for the LSE)
+    const uint16_t* kmp = (p.km && p.lse) ? p.km + ((int64_t)b * p.Hk + hk) * D + 16 * hh : nullptr;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll

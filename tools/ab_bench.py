@@ -45,15 +45,15 @@ if a.pv == "fp8":
 ref = None
 variants = []
 for spec in a.libs:
-    path, nw, shape = (spec.split("@") + ["", ""])[:3]   # lib.so[@nwaves[@mfma shape 16|32]]
+    path, nw = (spec.split("@") + [""])[:2]   # lib.so[@nwaves]
     l = ctypes.CDLL(os.path.abspath(path))
     for name, (res, args) in L.SIGNATURES.items():
         if hasattr(l, name):
             fn = getattr(l, name); fn.restype, fn.argtypes = res, args
-    variants.append((spec, l, (int(nw) if nw else 0, int(shape) if shape else 0)))
+    variants.append((spec, l, int(nw) if nw else 0))
 st = torch.cuda.current_stream().cuda_stream
-def run(l, tune):
-    l.sage_set_tuning(0, tune[0])
+def run(l, nw):
+    l.sage_set_tuning(0, nw)
     if a.pv == "fp8":
         r = l.sage_attn_qk_int8_pv_f8(L.desc(q8, "HND"), L.desc(k8, "HND"), vd, L.desc(o, "HND"), EL, qs.data_ptr(),
                                       ks.data_ptr(), vs.data_ptr(), None, None, B, H, H, N, N, D, int(causal), 3, 128, 32,

@@ -9,9 +9,17 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in c3 c2 c4; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-fa2 > $OUT/kt_$wl.log 2>&1
+  # bench.py's OWN windows (c2: 200 timed steps after 20 warm-up steps -- the steady state its JSON line quotes; c3/c4: 20 + 5)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$wl -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-fa2 > $OUT/kt_$wl.log 2>&1
   cp $(ls $OUT/kt_$wl/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${wl}_kernel_stats.csv
+  tail -1 $OUT/kt_$wl.log > $OUT/${TAG}_bench_${wl}_under_tracer.json
 done
+# the attention kernels alone over the sweep's shapes (all head_dim-64 and -128 rows, FP16 and FP8 PV): steady state
+# (30 back-to-back launches per shape) and isolated launches (synchronise + 3 ms pause before each)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_sweep -- python3 $R/tools/sweep_kernels.py 30 > $OUT/kt_sweep.log 2>&1
+python3 $R/tools/trace_summary.py $OUT/kt_sweep 3 > $OUT/${TAG}_sweep_kernel_durations.md
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_sweep_iso -- python3 $R/tools/sweep_kernels.py 12 --isolated > $OUT/kt_sweep_iso.log 2>&1
+python3 $R/tools/trace_summary.py $OUT/kt_sweep_iso 3 > $OUT/${TAG}_sweep_kernel_durations_isolated.md
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $OUT/pmc_write -- python3 $R/tools/run_attn.py c3 3 > $OUT/pmc_write.log 2>&1
