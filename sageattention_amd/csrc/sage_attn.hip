@@ -917,13 +917,24 @@ void attn_i8_kernel(const AttnParams p) {
       };
 #define SAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
       v4i kf = kf_early;
+      // head_dim 64: K fragments are read TWO S MFMAs ahead (two registers in flight; four S MFMAs per tile, one per region,
+      // so one-ahead left the read ~70 cycles).  Round 3, long windows, bit-identical: C2 +0.75 %, (4,32,8192,64) +0.8 %,
+      // C2-causal +0.3 %; head_dim 128 (eight S MFMAs, two per region): -0.3 % -> not there.
+      constexpr bool KPREF2 = D == 64;
+      v4i kfq[2] = {kf_early, kf_early};
+      if constexpr (KPREF2 && NEXT != 2) kfq[1] = k_frag(1);
       v8h vf[DT], vn[DT], pf, pn;
       // region 0: P(quarter 0) beside the first S MFMAs; V^T fragments of quarter 0
 #pragma unroll
       for (int g = 0; g < SPR; ++g) {
         if constexpr (NEXT != 2) {
-          s_step(g, kf);
-          kf = k_frag(g + 1);
+          if constexpr (KPREF2) {
+            s_step(g, kfq[g & 1]);
+            if (g + 2 < NS) kfq[g & 1] = k_frag(g + 2);
+          } else {
+            s_step(g, kf);
+            kf = k_frag(g + 1);
+          }
         }
 #pragma unroll
         for (int dt = g * (DT / SPR); dt < (g + 1) * (DT / SPR); ++dt) vf[dt] = v_frag(0, dt);
@@ -949,8 +960,13 @@ void attn_i8_kernel(const AttnParams p) {
           }
           SAGE_FENCE();
           if (NEXT != 2 && (dt + 1) % (DT / SPR) == 0) {
-            s_step(si, kf);
-            if (si + 1 < NS) kf = k_frag(si + 1);
+            if constexpr (KPREF2) {
+              s_step(si, kfq[si & 1]);
+              if (si + 2 < NS) kfq[si & 1] = k_frag(si + 2);
+            } else {
+              s_step(si, kf);
+              if (si + 1 < NS) kf = k_frag(si + 1);
+            }
             ++si;
             SAGE_FENCE();
           }
