@@ -73,8 +73,8 @@ _GRAN_CODE = {"per_block": L.GRAN_PER_BLOCK, "per_block_cuda": L.GRAN_PER_BLOCK,
 # Fold the Q quantizer into the attention kernel (sage_attn_fusedq_*): same bits, one launch and one pass over Q less.
 # Re-measured end to end in round 3 (tools/fuseq_bench.py, profiles/r03_ab/fuseq_crossover.log), after the prologue learnt
 # to issue its tile copies before the Q loads: fused <= separate at every length -- 0.96-0.97 at 2K keys, 0.98-1.00 at 4K,
-# 0.993 (fp16 PV) / 0.994 (fp8 PV) at C3, 0.995 / 0.992 at C4 -- so there is no length limit any more (round 2 stopped at
-# 4096 rows, where the two paths then tied).  Default ON since round 2: the rare wrong 32-row wave seen under perturbed
+# 0.993 (fp16 PV) / 0.994 (fp8 PV) at C3, 0.995 / 0.992 at C4; cross-attention with 16K-32K query rows on 256-4096 keys
+# (tools/cross_bench.py): 1.00-1.11x faster fused -- so there is no length limit any more (round 2 stopped at 4096 rows).  Default ON since round 2: the rare wrong 32-row wave seen under perturbed
 # timing in round 1 was an LDS race in the attention kernel's prologue, fixed by one barrier
 # (profiles/r02_race_evidence.md).  SAGEATTN_FUSE_Q=0 selects the stand-alone Q quantizer + kernel path (bit-identical).
 FUSE_Q_QUANT = os.environ.get("SAGEATTN_FUSE_Q", "1") == "1"

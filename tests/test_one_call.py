@@ -66,3 +66,21 @@ def test_one_call_nwaves_is_per_call():
         assert lib.sage_get_tuning(0) == 0      # the calling thread's setting is untouched
         outs.append(o)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])  # geometry never changes results
+
+
+@pytest.mark.parametrize("pv", ["fp16", "fp8"])
+def test_custom_sm_scale_and_padded_head_dim_vs_oracle(pv):
+    """A caller-chosen sm_scale and a head_dim that is padded (96 -> 128, sm_scale from the ORIGINAL head_dim, core.py:606)
+    through the default (one-call) path against the oracle's end-to-end restatement."""
+    import sageattention_amd as sa
+    from oracle import sage_oracle as O
+    torch.manual_seed(3)
+    for D, sm in ((64, 0.2), (96, None), (128, 0.05)):
+        q, k, v = (torch.randn(1, 4, 300, D).to(torch.float16) for _ in range(3))
+        fn = sa.sageattn_qk_int8_pv_fp16_cuda if pv == "fp16" else sa.sageattn_qk_int8_pv_fp8_cuda
+        o, lse = fn(q.cuda(), k.cuda(), v.cuda(), sm_scale=sm, return_lse=True)
+        torch.cuda.synchronize()
+        oo, ol = O.sageattn_oracle(q, k, v, qk_quant_gran="per_thread", pv=pv, sm_scale=sm, return_lse=True)
+        assert o.shape == q.shape
+        assert (o.cpu().float() - oo.float()).abs().max() < (2e-3 if pv == "fp16" else 0.06), (D, sm)
+        assert (lse.cpu() - ol).abs().max() < 2e-3, (D, sm)
