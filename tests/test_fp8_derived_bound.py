@@ -27,7 +27,9 @@ LOG2E = 1.44269504
 
 # The three out-of-tolerance configurations the random sweep found (tools/random_parity_sweep.py; (seed, index, maxlen) of
 # tests/sweep_configs.py names shapes, flags and tensors): |o - oracle| 0.091 / 0.076 / 0.0625 against the flat 0.06 ...
-SWEEP_CASES = [(77, 297, 900), (5, 35, 200), (5, 59, 200)]
+SWEEP_CASES = [(77, 297, 900), (5, 35, 200), (5, 59, 200),
+               # round-3 sweeps of the final library (seeds 301-303, 1 050 configurations): four more of the same class
+               (301, 50, 900), (302, 335, 900), (303, 257, 900), (303, 315, 900)]
 # ... and short shapes in which EVERY row has few keys
 SHORT_CASES = [
     dict(layout="NHD", dt=torch.bfloat16, Hq=4, Hk=2, D=128, causal=True, M=7, N=7, B=2, gran="per_warp", smooth_k=True, nw=4, kbias=2.0, seed=5),
@@ -55,7 +57,6 @@ def test_fp8_pv_within_the_derived_rounding_bound(c):
     from sweep_configs import tensors
     layout, dt, Hq, Hk, D, causal, M, N, gran, smooth_k, nw = (c[x] for x in ("layout", "dt", "Hq", "Hk", "D", "causal", "M", "N",
                                                                               "gran", "smooth_k", "nw"))
-    assert D in (64, 128)
     q, k, v = tensors(c)
     L.lib().sage_set_tuning(0, nw)
     try:
@@ -66,26 +67,12 @@ def test_fp8_pv_within_the_derived_rounding_bound(c):
         L.lib().sage_set_tuning(0, 0)
     oo, ol = O.sageattn_oracle(q, k, v, tensor_layout=layout, is_causal=causal, qk_quant_gran=gran, pv="fp8", smooth_k=smooth_k,
                                return_lse=True)
-    hnd = (lambda x: x) if layout == "HND" else (lambda x: x.transpose(1, 2))
-    # the quantized operands both sides multiply (quantizers are bit-exact: test_gpu_parity.py) and the weights they approximate
-    km = O.k_mean(k, layout) if smooth_k else None
-    quant = O.per_thread_int8 if gran == "per_thread" else O.per_warp_int8
-    q8, qs, k8, ks = quant(q, k, km, tensor_layout=layout)
-    W = softmax_weights(hnd(q8), hnd(k8), O.expand_q_scale(qs, M, gran), O.expand_k_scale(ks, N, gran), D ** -0.5 * LOG2E, causal)
-    v8, v_scale, _ = O.per_channel_fp8(v, tensor_layout=layout, smooth_v=False)
-    v8h = v8 if layout == "HND" else v8.transpose(1, 2)                                   # [B,Hk,D,Npad]
-    v_deq = (v8h.float()[..., :N] * v_scale.unsqueeze(-1)).transpose(2, 3)                # [B,Hk,N,D]
-    wv = W @ v_deq.abs().repeat_interleave(Hq // Hk, dim=1)
-    of, oof = hnd(o.cpu()).float(), hnd(oo).float()
-    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
-    bound = 2.0 ** -3 * wv + 2 * ulp * oof.abs().clamp(min=0.25)
-    assert ((of - oof).abs() <= bound).all(), ((of - oof).abs() / bound).max()
-    # rows with many keys: the roundings average out.  Each of the two roundings errs uniformly within +-2^-4 relative
-    # (variance 2^-8 / 3), independently per key: sigma^2 = (2 * 2^-8 / 3) * sum((p v)^2) / l^2 per element.  6 sigma holds for
-    # every one of the ~1e5 elements of a case (it is the tighter bound from a few dozen keys on; the flat 0.06 of the
-    # operator's other tests is this bound for typical rows)
-    sigma = torch.sqrt((2.0 ** -7 / 3) * ((W * W) @ (v_deq * v_deq).repeat_interleave(Hq // Hk, dim=1)))
-    stat = 6 * sigma + 2 * ulp * oof.abs().clamp(min=0.25)
-    assert ((of - oof).abs() <= torch.minimum(bound, stat)).all(), ((of - oof).abs() / torch.minimum(bound, stat)).max()
+    # |o - oracle| / bound over all elements, bound = min(2^-3 (W |v_deq|), 6 sigma) + 2 output ulps: the hard form for rows with
+    # few keys (each of the two roundings errs by at most 2^-4 of p), the 6-sigma form of the same rounding model (uniform
+    # errors, variance 2^-8 / 3 each, independent per key) where a row has enough keys to average -- the flat 0.06 of the
+    # operator's other tests is that bound for typical rows.  Shared with tools/random_parity_sweep.py (sweep_configs.py).
+    from sweep_configs import fp8_bound_ratio
+    ratio = fp8_bound_ratio(c, q, k, v, o.cpu(), oo)
+    assert ratio <= 1.0, ratio
     # the LSE does not see P's rounding: fp32 sums of the unrounded p on both sides
     assert (lse.cpu() - ol).abs().max() < 3e-3

@@ -6,7 +6,7 @@ import torch
 import sageattention_amd as sa
 from oracle import sage_oracle as O
 from sageattention_amd import _lib as L
-from sweep_configs import configs, tensors
+from sweep_configs import configs, fp8_bound_ratio, tensors
 seed0 = int(sys.argv[1]); count = int(sys.argv[2])
 maxlen = int(sys.argv[3]) if len(sys.argv) > 3 else 900
 t0 = time.time(); worst = {}
@@ -28,5 +28,10 @@ for c in configs(seed0, count, maxlen):
     eo = (o.cpu().float() - oo.float()).abs().max().item(); el = (lse.cpu() - ol).abs().max().item()
     key = (pv, str(dt)); worst[key] = max(worst.get(key, 0), eo)
     if not (o.shape == q.shape and torch.isfinite(o).all() and eo < tol and el < 3e-3):
-        print("FAIL", (seed0, c["it"], maxlen), {k_: str(v_) for k_, v_ in c.items()}, eo, el, flush=True)
+        note = ""
+        if pv == "fp8" and o.shape == q.shape and torch.isfinite(o).all() and el < 3e-3:
+            # over the FLAT tolerance: inside the bound DERIVED from e4m3's rounding (rows with few keys)?
+            r = fp8_bound_ratio(c, q, k, v, o.cpu(), oo)
+            note = f" derived-bound ratio {r:.2f}" + (" (inside: a few-key row, not a failure)" if r <= 1 else " (OUTSIDE)")
+        print("FAIL" if "OUTSIDE" in note or not note else "OVER-FLAT", (seed0, c["it"], maxlen), {k_: str(v_) for k_, v_ in c.items()}, eo, el, note, flush=True)
 print("done", count, "configs in", round(time.time() - t0, 1), "s; worst |o - oracle| per (pv, dtype):", worst)
