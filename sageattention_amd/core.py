@@ -350,7 +350,7 @@ def sageattn_qk_int8_pv_fp8_cuda(
             return (o, lse) if return_lse else o
         o = torch.empty(q.size(), dtype=dtype, device=q.device)
         if smooth_k and not smooth_v and k.shape == v.shape and k.dtype == v.dtype:
-            # the default configuration: K and V prepared by one call (two launches instead of five up to 4096 keys)
+            # the default configuration: K and V prepared by one call (two launches at every length)
             gran, rnd = _k_pairing(qk_quant_gran)
             k8, ks, km, v8, v_scale = kv_prepare_fp8(k, v, tensor_layout, gran, rnd, scale_max=448.0)
             vm = None

@@ -67,8 +67,8 @@ def k_mean(k: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
 
 def k_smooth_quant(k: torch.Tensor, tensor_layout: str, gran: int, rounding: int, dense_heads: bool = True):
     """``km = k.mean(seq)`` (core.py:612) and the INT8 quantization of ``k - km`` (K half of core.py:621-624) as one call
-    of the library (sage_k_smooth_quant): bit-identical to ``k_mean`` + ``_quant(..., mean=km)``, one launch less for
-    sequences up to 4096 rows.  Returns (k_int8, k_scale, km [B,H,D])."""
+    of the library (sage_k_smooth_quant): bit-identical to ``k_mean`` + ``_quant(..., mean=km)``, two launches at every
+    length (the quantizer finishes the mean from at most 16 chunk sums).  Returns (k_int8, k_scale, km [B,H,D])."""
     B, H, N, D = L.dims(k, tensor_layout)
     if dense_heads and tensor_layout == "NHD":
         out = torch.empty((B, H, N, D), dtype=torch.int8, device=k.device).transpose(1, 2)
@@ -87,7 +87,7 @@ def k_smooth_quant(k: torch.Tensor, tensor_layout: str, gran: int, rounding: int
 
 def kv_prepare_fp8(k: torch.Tensor, v: torch.Tensor, tensor_layout: str, gran: int, rounding: int, scale_max: float = 448.0):
     """The K/V side of the FP8-PV operator's pre-pass as one call of the library (sage_kv_prepare_fp8): ``k_smooth_quant(k)``
-    and ``per_channel_fp8(v, smooth_v=False)``, bit-identical to them, two launches instead of five up to 4096 rows.
+    and ``per_channel_fp8(v, smooth_v=False)``, bit-identical to them, two launches at every length (five separate ones before).
     Returns (k_int8, k_scale, km, v_fp8, v_scale)."""
     B, H, N, D = L.dims(k, tensor_layout)
     assert L.dims(v, tensor_layout) == (B, H, N, D), "k and v must have the same shape"
