@@ -6,6 +6,7 @@
 // Roofline: HBM. Algorithmic traffic per element: 2 B read + 1 B written (K1), 2 B read (K0).
 // Every thread moves 16 B per load (8 fp16/bf16), the widest coalesced access on CDNA4.
 // Compiled with -ffp-contract=off: the integer outputs must match the oracle bit for bit.
+#include <type_traits>
 #include "sage_common.h"
 #include "sage_fp8_kernels.h"
 
@@ -36,15 +37,30 @@ __device__ __forceinline__ void k_mean_partial_body(const uint16_t* __restrict__
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int rows = kmean_chunk_rows(N);
   const int r0 = s * rows;
-#pragma unroll 4
-  for (int i = 0; i < rows / RPP; ++i) {
-    const int row = r0 + i * RPP + tr;
-    if (row < N) {
-      const uint4 u = *reinterpret_cast<const uint4*>(base + (int64_t)row * sn);
+  // Whole chunks (all but the last of a sequence) take the loop without a row test: hipcc sinks a conditional load into
+  // its branch and then waits for every load before it issues the next one (one 16-B load in flight per thread: the kernel
+  // ran at the latency of sixteen dependent round trips); unconditional, the unrolled loop keeps eight in flight.  Same
+  // additions in the same order.
+  if (r0 + rows <= N) {
+#pragma unroll 8
+    for (int i = 0; i < rows / RPP; ++i) {
+      const uint4 u = *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + i * RPP + tr) * sn);
       float f[8];
       unpack8<BF16>(u, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+  } else {
+#pragma unroll 4
+    for (int i = 0; i < rows / RPP; ++i) {
+      const int row = r0 + i * RPP + tr;
+      if (row < N) {
+        const uint4 u = *reinterpret_cast<const uint4*>(base + (int64_t)row * sn);
+        float f[8];
+        unpack8<BF16>(u, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      }
     }
   }
 #pragma unroll
@@ -111,6 +127,23 @@ struct QuantParams {
   uint16_t* km_out;
 };
 
+// max over the TPR (8 or 16) consecutive lanes that hold one row, on DPP (quad swaps, then the mirrored half rows / rows): every
+// lane ends with the row's maximum; 3-4 v_max_f32_dpp instead of as many ds_bpermute round trips.  (A maximum does not depend
+// on the order it is taken in: bit-identical to the xor butterfly.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int TPR>
+__device__ __forceinline__ float row_lanes_max(float a) {
+  static_assert(TPR == 8 || TPR == 16, "a row is 8 or 16 lanes");
+  a = fmaxf(a, dpp_lane<0xB1>(a));    // quad_perm [1,0,3,2]
+  a = fmaxf(a, dpp_lane<0x4E>(a));    // quad_perm [2,3,0,1]
+  a = fmaxf(a, dpp_lane<0x141>(a));   // row_half_mirror: the other quad of the 8 lanes
+  if constexpr (TPR == 16) a = fmaxf(a, dpp_lane<0x140>(a));  // row_mirror: the other half of the 16 lanes
+  return a;
+}
+
 __device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int warp_shift) {
   // group-id maps: per_block: all rows of the workgroup; per_warp: lr/warp; per_thread:
   // triton/quant_per_thread.py:27-36 (Q: r%8) and :73-80 (K: (r%8)/2).
@@ -120,66 +153,92 @@ __device__ __forceinline__ int group_of_row(int lr, int gran, int is_key, int wa
   return is_key ? w * 4 + ((lr & 7) >> 1) : w * 8 + (lr & 7);
 }
 
-// block `blk` (BLK rows) of head (b, h) of H.  LDS: gmax = 64 dwords, mpart = 16 x D floats (16-byte aligned)
-template <int D, int BLK, bool BF16>
-__device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const int blk, const int h, const int b, const int H,
-                                                   unsigned int* gmax, float (*mpart)[D]) {
-  constexpr int TPR = D / 8;
-  constexpr int RPP = 256 / TPR;
-  constexpr int NP = BLK / RPP;
+// ---- the quantizer in three steps, shared by the one-block-per-workgroup kernels and the streaming K quantizer ----
+template <int D, int BLK>
+struct QuantGeom {
+  static constexpr int TPR = D / 8;        // threads per row (16 B each)
+  static constexpr int RPP = 256 / TPR;    // rows per pass of the workgroup
+  static constexpr int NP = BLK / RPP;     // passes per block = 16-B loads per thread
   static_assert(NP >= 1, "block too small");
-  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
-  int N_ = p.N;
-  int64_t x_boff = b * p.xsb, o_boff = b * p.osb;
-  if (p.cu) {
-    const int lo = p.cu[b];
-    N_ = p.cu[b + 1] - lo;
-    if (blk * BLK >= N_) return;  // uniform for the workgroup
-    x_boff = (int64_t)lo * p.xsn;
-    o_boff = (int64_t)lo * p.osn;
-  }
+};
 
-  if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
-
-  // the block's rows first: everything below overlaps with this one trip to HBM
-  const uint16_t* xbase = p.x + x_boff + h * p.xsh + tc * 8;
-  float xf[NP][8];
-  uint4 raw[NP];
+// step 1: the rows of block `blk` (rows past the end read as zeros).  xbase: head base + this thread's column offset
+template <int D, int BLK>
+__device__ __forceinline__ void quant_load_rows(const uint16_t* xbase, const int64_t xsn, const int blk, const int N_,
+                                                uint4 (&raw)[QuantGeom<D, BLK>::NP]) {
+  using G = QuantGeom<D, BLK>;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // see quant_block
+  const int tr = tid / G::TPR;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int row = blk * BLK + i * RPP + tr;
+  for (int i = 0; i < G::NP; ++i) {
+    const int row = blk * BLK + i * G::RPP + tr;
     raw[i] = make_uint4(0, 0, 0, 0);
-    if (row < N_) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * p.xsn);
+    if (row < N_) raw[i] = *reinterpret_cast<const uint4*>(xbase + (int64_t)row * xsn);
   }
+}
+
+// step 2 (once per head): the mean as 8 storage-dtype values per thread column.  Holds the workgroup's FIRST barrier (which
+// also publishes the zeroed group maxima) and, in the mean_part form, a second one.  mpart: 16 x D floats (16-byte aligned)
+template <int D, bool BF16>
+__device__ __forceinline__ uint4 quant_mean_bits(const QuantParams& p, const int h, const int b, const int H, const bool store_km,
+                                                 float (*mpart)[D]) {
+  constexpr int TPR = D / 8;
+  const int tr = threadIdx.x / TPR, tc = threadIdx.x % TPR;
   // mean_part: thread row s fetches chunk s (ONE round trip to L2 for all S chunks instead of S dependent ones: at 2048
-  // rows the quantizer spent more time on these than on its block), LDS hands every thread all chunks
+  // rows the quantizer spent more time on these than on its block), LDS hands the first thread row all chunks
   if (p.mean_part && tr < p.S) {
     const float* pp = p.mean_part + (((int64_t)b * H + h) * p.S + tr) * D + tc * 8;
     *reinterpret_cast<float4*>(&mpart[tr][tc * 8]) = *reinterpret_cast<const float4*>(pp);
     *reinterpret_cast<float4*>(&mpart[tr][tc * 8 + 4]) = *reinterpret_cast<const float4*>(pp + 4);
   }
   __syncthreads();  // gmax zeroed, mpart filled
-
-  float mean_f[8];
+  // mean_part form: the FIRST thread row finishes the reduction (chunk order, as k_mean_final_kernel; an IEEE division per
+  // column) and hands the bits to the other rows through LDS -- every thread doing it for itself cost 8 divisions + 8 S
+  // adds per thread, a fifth of the kernel's vector work, and the rows of the block are still on their way from HBM.
+  uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
   if (p.mean_part) {
-    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s_ = 0; s_ < p.S; ++s_) {  // chunk order, as k_mean_final_kernel
-      const float4 a = *reinterpret_cast<const float4*>(&mpart[s_][tc * 8]), c = *reinterpret_cast<const float4*>(&mpart[s_][tc * 8 + 4]);
-      sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w; sum[4] += c.x; sum[5] += c.y; sum[6] += c.z; sum[7] += c.w;
-    }
-    uint32_t w[4];
+    if (tr == 0) {
+      float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int s_ = 0; s_ < p.S; ++s_) {
+        const float4 a = *reinterpret_cast<const float4*>(&mpart[s_][tc * 8]), c = *reinterpret_cast<const float4*>(&mpart[s_][tc * 8 + 4]);
+        sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w; sum[4] += c.x; sum[5] += c.y; sum[6] += c.z; sum[7] += c.w;
+      }
+      uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint16_t bits = f32_to_elem_bits<BF16>(sum[j] / (float)p.N);
-      mean_f[j] = elem_to_f32<BF16>(bits);
-      if (j & 1) w[j >> 1] |= (uint32_t)bits << 16; else w[j >> 1] = bits;
+      for (int j = 0; j < 8; ++j) {
+        const uint16_t bits = f32_to_elem_bits<BF16>(sum[j] / (float)p.N);
+        if (j & 1) w[j >> 1] |= (uint32_t)bits << 16; else w[j >> 1] = bits;
+      }
+      mbits = make_uint4(w[0], w[1], w[2], w[3]);
+      // (this thread alone read columns tc*8 .. tc*8+7 of mpart, so it may overwrite them in row 0)
+      *reinterpret_cast<uint4*>(&mpart[0][tc * 8]) = mbits;
+      if (store_km) *reinterpret_cast<uint4*>(p.km_out + ((int64_t)b * H + h) * D + tc * 8) = mbits;
     }
-    if (blk == 0 && tr == 0) *reinterpret_cast<uint4*>(p.km_out + ((int64_t)b * H + h) * D + tc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
+    mbits = *reinterpret_cast<const uint4*>(&mpart[0][tc * 8]);
   } else if (p.mean) {
     // packed sequences share one mean over all tokens ([1,H,D], core.py:461)
-    const uint4 um = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)(p.cu ? 0 : b) * H + h) * D + tc * 8);
-    unpack8<BF16>(um, mean_f);
+    mbits = *reinterpret_cast<const uint4*>(p.mean + ((int64_t)(p.cu ? 0 : b) * H + h) * D + tc * 8);
   }
+  return mbits;
+}
+
+// step 3: block `blk` from its rows: group maxima (gmax: 64 zeroed dwords), ONE barrier, scales, rounding, stores.
+// zero_next: 64 dwords zeroed behind the barrier (the streaming kernel's group maxima of the block after next), or null.
+// after_phase1(): runs when `raw` has been consumed (the streaming kernel reloads it with the next block's rows there)
+template <int D, int BLK, bool BF16, bool TRITON, typename AfterPhase1>
+__device__ __forceinline__ void quant_block(const QuantParams& p, const int blk, const int h, const int b, const int H, const int N_,
+                                            const int64_t o_boff, uint4 (&raw)[QuantGeom<D, BLK>::NP], const uint4 mbits,
+                                            unsigned int* gmax, unsigned int* zero_next, AfterPhase1 after_phase1) {
+  using G = QuantGeom<D, BLK>;
+  constexpr int TPR = G::TPR, RPP = G::RPP, NP = G::NP;
+  // (the thread id is made opaque per block: in the streaming kernel's loop hipcc otherwise hoists every row / group /
+  //  address term that depends only on it out of the loop and keeps ~40 registers alive for them)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int tr = tid / TPR, tc = tid % TPR;
+  float xf[NP][8];
   float dvec[8];
   if (p.dot_vec) {
     const int Hk = H / p.dot_group;
@@ -187,38 +246,59 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
     unpack8<BF16>(ud, dvec);
   }
 
+  // x - mean (no mean: mbits = 0 and x - 0 is x in either form), times the multiplier, and the group maxima
+  //   TRITON: `k - km` in the input dtype (torch).   CUDA: in fp32 (fused.cu).
+  // fp16, TRITON: the subtraction runs as v_pk_add_f16 -- the correctly rounded fp16 difference, which is what rounding the
+  // fp32 difference of two fp16 values gives as well (24 >= 2*11+2 bits: the double rounding is innocuous) -- 4 packed
+  // subtractions + 8 converts per 8 elements instead of 8 + 8 + 16.
+  {
+    float mean_f[8];
+    if constexpr (!TRITON || BF16) unpack8<BF16>(mbits, mean_f);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int lr = i * RPP + tr;
-    const int row = blk * BLK + lr;
-    const bool valid = row < N_;
-    unpack8<BF16>(raw[i], xf[i]);
-    if (p.dot_vec) {
-      float dot = 0.f;
+    for (int i = 0; i < NP; ++i) {
+      const int lr = i * RPP + tr;
+      const int row = blk * BLK + lr;
+      const bool valid = row < N_;
+      if (p.dot_vec) {
+        float xr[8];
+        unpack8<BF16>(raw[i], xr);
+        float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot += xf[i][j] * dvec[j];
+        for (int j = 0; j < 8; ++j) dot += xr[j] * dvec[j];
 #pragma unroll
-      for (int o = 1; o < TPR; o <<= 1) dot += __shfl_xor(dot, o);
-      if (tc == 0 && valid) p.dot_out[((int64_t)b * H + h) * p.N + row] = dot;
-    }
-    float amax = 0.f;
-    const float mult_row = valid ? p.mult : 0.f;  // rows past the end contribute zeros (finite inputs: raw is 0 there)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = xf[i][j];
-      if (p.mean || p.mean_part) {
-        v = v - mean_f[j];
-        if (p.rounding == SAGE_ROUND_TRITON) v = round_to_elem<BF16>(v);  // torch `k - km` in the input dtype
+        for (int o = 1; o < TPR; o <<= 1) dot += __shfl_xor(dot, o);
+        if (tc == 0 && valid) p.dot_out[((int64_t)b * H + h) * p.N + row] = dot;
       }
-      v = v * mult_row;
-      xf[i][j] = v;
-      amax = fmaxf(amax, fabsf(v));
-    }
+      if constexpr (TRITON && !BF16) {
+        const uint32_t xw[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w}, mw[4] = {mbits.x, mbits.y, mbits.z, mbits.w};
 #pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (tc == 0) atomicMax(&gmax[group_of_row(lr, p.gran, p.is_key, p.warp_shift)], __float_as_uint(amax));
+        for (int w = 0; w < 4; ++w) {
+          const v2h d = __builtin_bit_cast(v2h, xw[w]) - __builtin_bit_cast(v2h, mw[w]);
+          xf[i][2 * w] = (float)d[0];
+          xf[i][2 * w + 1] = (float)d[1];
+        }
+      } else {
+        unpack8<BF16>(raw[i], xf[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xf[i][j] = xf[i][j] - mean_f[j];
+          if constexpr (TRITON) xf[i][j] = round_to_elem<BF16>(xf[i][j]);
+        }
+      }
+      float amax = 0.f;
+      const float mult_row = valid ? p.mult : 0.f;  // rows past the end contribute zeros (finite inputs: raw is 0 there)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xf[i][j] = xf[i][j] * mult_row;
+        amax = fmaxf(amax, fabsf(xf[i][j]));
+      }
+      amax = row_lanes_max<TPR>(amax);
+      if (tc == 0) atomicMax(&gmax[group_of_row(lr, p.gran, p.is_key, p.warp_shift)], __float_as_uint(amax));
+    }
   }
+  after_phase1();
   __syncthreads();
+  if (zero_next && threadIdx.x < 64) zero_next[threadIdx.x] = 0u;
 
   const int groups_per_blk = p.gran == SAGE_GRAN_PER_BLOCK ? 1
                              : p.gran == SAGE_GRAN_PER_WARP ? BLK >> p.warp_shift
@@ -226,7 +306,7 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
   const float eps = (p.gran == SAGE_GRAN_PER_THREAD) ? 0.0000001f : 0.f;
   if (threadIdx.x < groups_per_blk) {
     const float a = __uint_as_float(gmax[threadIdx.x]);
-    const float sc = (p.rounding == SAGE_ROUND_TRITON) ? a / 127.f + eps : fmaxf(a, 0.0000001f) / 127.f;
+    const float sc = TRITON ? a / 127.f + eps : fmaxf(a, 0.0000001f) / 127.f;
     p.scale[b * p.ss_b + h * p.ss_h + blk * p.ss_blk + threadIdx.x] = sc;
   }
 
@@ -237,7 +317,9 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
     const int row = blk * BLK + lr;
     const float a = __uint_as_float(gmax[group_of_row(lr, p.gran, p.is_key, p.warp_shift)]);
     int q[8];
-    if (p.rounding == SAGE_ROUND_TRITON) {
+    // No clamp on the two fast paths: |x| <= a (a is the maximum of a group x belongs to), so |x * r| <= 127 (1 + 3 ulp)
+    // and rint() of it is at most 127 in magnitude.
+    if constexpr (TRITON) {
       // q = trunc(x/sc + 0.5*sign) with an IEEE division (quant_per_block.py:42-44).  The division costs ~10 VALU
       // ops per element and made this HBM-bound kernel VALU-bound, so: multiply by the correctly rounded reciprocal
       // (|x*r - x/sc| <= 1.5 ulp <= 2.3e-5 for |x/sc| <= 127, plus <= 7.6e-6 from the +0.5) and fall back to the exact
@@ -253,7 +335,7 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
         for (int j = 0; j < 8; ++j) {
           float y = xf[i][j] / sc;  // IEEE division
           y = y + (y >= 0.f ? 0.5f : -0.5f);
-          q[j] = (int)y;  // truncation, as tl `.to(int8)`
+          q[j] = min(max((int)y, -128), 127);  // truncation, as tl `.to(int8)`
         }
       }
     } else {
@@ -261,18 +343,74 @@ __device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const i
 #pragma unroll
       for (int j = 0; j < 8; ++j) q[j] = (int)rintf(xf[i][j] * inv);  // cvt.rni (fused.cu:176-181)
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = min(max(q[j], -128), 127);
     const uint32_t w0 = pack_i8x4(q[0], q[1], q[2], q[3]), w1 = pack_i8x4(q[4], q[5], q[6], q[7]);
     if (row < N_) *reinterpret_cast<uint2*>(obase + (int64_t)lr * p.osn) = make_uint2(w0, w1);
   }
 }
 
-template <int D, int BLK, bool BF16>
-__global__ __launch_bounds__(256) void quant_qk_int8_kernel(const QuantParams p) {
+// block `blk` (BLK rows) of head (b, h) of H.  LDS: gmax = 64 dwords, mpart = 16 x D floats (16-byte aligned)
+template <int D, int BLK, bool BF16, bool TRITON>
+__device__ __forceinline__ void quant_qk_int8_body(const QuantParams& p, const int blk, const int h, const int b, const int H,
+                                                   unsigned int* gmax, float (*mpart)[D]) {
+  int N_ = p.N;
+  int64_t x_boff = b * p.xsb, o_boff = b * p.osb;
+  if (p.cu) {
+    const int lo = p.cu[b];
+    N_ = p.cu[b + 1] - lo;
+    if (blk * BLK >= N_) return;  // uniform for the workgroup
+    x_boff = (int64_t)lo * p.xsn;
+    o_boff = (int64_t)lo * p.osn;
+  }
+  if (threadIdx.x < 64) gmax[threadIdx.x] = 0u;
+  // the block's rows first: everything below overlaps with this one trip to HBM
+  uint4 raw[QuantGeom<D, BLK>::NP];
+  quant_load_rows<D, BLK>(p.x + x_boff + h * p.xsh + (threadIdx.x % (D / 8)) * 8, p.xsn, blk, N_, raw);
+  const uint4 mbits = quant_mean_bits<D, BF16>(p, h, b, H, blk == 0, mpart);
+  quant_block<D, BLK, BF16, TRITON>(p, blk, h, b, H, N_, o_boff, raw, mbits, gmax, nullptr, [] {});
+}
+
+// (the rounding flavour is a template parameter: with both flavours in one kernel the register allocation of the shared
+//  part suffered -- 80 instead of 65 registers at head_dim 128 -- and every element paid a uniform branch)
+template <int D, int BLK, bool BF16, bool TRITON>
+__global__ __launch_bounds__(256, BLK * D <= 64 * 128 ? 7 : 4) void quant_qk_int8_kernel(const QuantParams p) {
   __shared__ unsigned int gmax[64];
   __shared__ __attribute__((aligned(16))) float mpart[16][D];  // chunk sums of the mean (mean_part form: S <= 16 <= RPP)
-  quant_qk_int8_body<D, BLK, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gmax, mpart);
+  quant_qk_int8_body<D, BLK, BF16, TRITON>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gmax, mpart);
+}
+
+// Streaming K quantizer (dense K, 64-row blocks): a workgroup walks `per_wg` consecutive blocks of ONE head and loads the
+// rows of block i+1 before it works on block i.  With one block per workgroup a launch is one (or two) generations of
+// workgroups that all sit in the same phase -- every load of the tensor issued at once, then every store -- and the
+// latency chain load -> maxima -> barrier -> rounding -> store is paid once per generation with nothing beside it; here
+// the next block's rows fly during the second half of the chain, stores and loads of neighbouring blocks overlap, and the
+// mean of the head is finished once per workgroup instead of once per block.  Same arithmetic per block: bit-identical.
+// One barrier per block: the group maxima rotate through three buffers (block i accumulates into buffer i % 3 and, behind
+// its barrier, zeroes buffer (i + 2) % 3 -- last read by block i-1, whose readers have all passed this barrier, and next
+// written by block i+2, behind the barrier of block i+1).
+template <int D, bool BF16, bool TRITON>
+__global__ __launch_bounds__(256, D == 64 ? 5 : 4) void k_quant_stream_kernel(const QuantParams p, const int per_wg) {
+  constexpr int BLK = 64;
+  using G = QuantGeom<D, BLK>;
+  __shared__ unsigned int gmax[3][64];
+  __shared__ __attribute__((aligned(16))) float mpart[16][D];
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int nblk = (p.N + BLK - 1) / BLK;
+  const int blk0 = blockIdx.x * per_wg, blk1 = min(blk0 + per_wg, nblk);  // the host launches no empty workgroup
+  if (threadIdx.x < 192) (&gmax[0][0])[threadIdx.x] = 0u;
+  const uint16_t* xbase = p.x + b * p.xsb + h * p.xsh + (threadIdx.x % G::TPR) * 8;
+  const int64_t o_boff = b * p.osb;
+  uint4 raw[G::NP];
+  quant_load_rows<D, BLK>(xbase, p.xsn, blk0, p.N, raw);
+  const uint4 mbits = quant_mean_bits<D, BF16>(p, h, b, H, blockIdx.x == 0, mpart);
+  int par = 0;
+  for (int blk = blk0; blk < blk1; ++blk) {
+    // the rows of the next block are requested as soon as this block's are unpacked (their registers are free then) and
+    // fly during the barrier, the rounding and the stores of this block
+    quant_block<D, BLK, BF16, TRITON>(p, blk, h, b, H, p.N, o_boff, raw, mbits, gmax[par], gmax[par == 0 ? 2 : par - 1], [&] {
+      if (blk + 1 < blk1) quant_load_rows<D, BLK>(xbase, p.xsn, blk + 1, p.N, raw);
+    });
+    par = par == 2 ? 0 : par + 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -305,14 +443,24 @@ __device__ __forceinline__ void v_amax_partial_body(const uint16_t* __restrict__
   const uint16_t* base = v + b * sb + h * sh + tc * 8;
   float am[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rows in [N, ceil16(N)) count as zeros (fused.cu:335): the same as starting at 0
   const int rows = kmean_chunk_rows(N);
-#pragma unroll 4
-  for (int i = 0; i < rows / RPP; ++i) {
-    const int row = s * rows + i * RPP + tr;
-    if (row < N) {
+  if ((s + 1) * rows <= N) {  // whole chunk: unconditional loads, eight in flight (see k_mean_partial_body)
+#pragma unroll 8
+    for (int i = 0; i < rows / RPP; ++i) {
       float f[8];
-      unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
+      unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)(s * rows + i * RPP + tr) * sn), f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) am[j] = fmaxf(am[j], fabsf(f[j]));
+    }
+  } else {
+#pragma unroll 4
+    for (int i = 0; i < rows / RPP; ++i) {
+      const int row = s * rows + i * RPP + tr;
+      if (row < N) {
+        float f[8];
+        unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) am[j] = fmaxf(am[j], fabsf(f[j]));
+      }
     }
   }
 #pragma unroll
@@ -336,7 +484,7 @@ __global__ __launch_bounds__(256) void kv_partial_kernel(const uint16_t* __restr
   else v_amax_partial_body<D, BF16>(v, vsb, vsh, vsn, N, vpart, S, x - S, blockIdx.y, blockIdx.z, gridDim.y, red);
 }
 
-template <int D, bool BF16>
+template <int D, bool BF16, bool TRITON>
 __global__ __launch_bounds__(256, D == 64 ? 8 : 7) void kv_quant_kernel(const QuantParams p, const VPrepParams q, const int nblk_k) {
   using G = VQuantGeom<D>;
   __shared__ unsigned int gmax[64];
@@ -344,7 +492,7 @@ __global__ __launch_bounds__(256, D == 64 ? 8 : 7) void kv_quant_kernel(const Qu
   __shared__ __attribute__((aligned(16))) uint32_t tile[G::BLKS * G::IMG];
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   if ((int)blockIdx.x < nblk_k) {
-    quant_qk_int8_body<D, 64, BF16>(p, blockIdx.x, h, b, H, gmax, exch);
+    quant_qk_int8_body<D, 64, BF16, TRITON>(p, blockIdx.x, h, b, H, gmax, exch);
     return;
   }
   const int bx = blockIdx.x - nblk_k;
@@ -475,7 +623,11 @@ static int quant_impl(const sage_tensor* x, int dtype, int B, int H, int N, int 
   dim3 grid(nblk, H, B);
   hipStream_t st = (hipStream_t)stream;
   launch_begin();
-#define LAUNCH(DD, BL, BF) hipLaunchKernelGGL((quant_qk_int8_kernel<DD, BL, BF>), grid, dim3(256), 0, st, p)
+#define LAUNCH(DD, BL, BF)                                                                                              \
+  do {                                                                                                                  \
+    if (rounding == SAGE_ROUND_TRITON) hipLaunchKernelGGL((quant_qk_int8_kernel<DD, BL, BF, true>), grid, dim3(256), 0, st, p);  \
+    else hipLaunchKernelGGL((quant_qk_int8_kernel<DD, BL, BF, false>), grid, dim3(256), 0, st, p);                      \
+  } while (0)
 #define BY_DT(DD, BL) do { if (dtype == SAGE_BF16) LAUNCH(DD, BL, true); else LAUNCH(DD, BL, false); } while (0)
   if (D == 64) { if (blk == 64) BY_DT(64, 64); else BY_DT(64, 128); }
   else { if (blk == 64) BY_DT(128, 64); else BY_DT(128, 128); }
@@ -528,6 +680,30 @@ extern "C" int sage_quant_k_int8_kvtiles(const sage_tensor* k, int dtype, int B,
                     out_tile_stride, scale_strides);
 }
 
+// Blocks per workgroup of the streaming K quantizer: as many as leave about as many workgroups per CU as its registers allow
+// to be resident (five at head_dim 64, four at 128), so that every workgroup is resident from the start and streams its share
+// of a head.
+static int k_quant_blocks_per_wg(int B, int H, int N, int D) {
+  const int64_t nblk = (N + 63) / 64, total = (int64_t)B * H * nblk, target = 256 * (D == 64 ? 5 : 4);
+  const int64_t per = (total + target - 1) / target;
+  return (int)(per < 1 ? 1 : per > nblk ? nblk : per);
+}
+
+static int launch_k_quant(const QuantParams& p, int dtype, int B, int H, int N, int D, hipStream_t st) {
+  const int nblk = (N + 63) / 64, per_wg = k_quant_blocks_per_wg(B, H, N, D);
+  const dim3 grid((nblk + per_wg - 1) / per_wg, H, B);
+  launch_begin();
+#define LAUNCH(DD, BF)                                                                                                  \
+  do {                                                                                                                  \
+    if (p.rounding == SAGE_ROUND_TRITON) hipLaunchKernelGGL((k_quant_stream_kernel<DD, BF, true>), grid, dim3(256), 0, st, p, per_wg);  \
+    else hipLaunchKernelGGL((k_quant_stream_kernel<DD, BF, false>), grid, dim3(256), 0, st, p, per_wg);                 \
+  } while (0)
+  if (D == 64) { if (dtype == SAGE_BF16) LAUNCH(64, true); else LAUNCH(64, false); }
+  else { if (dtype == SAGE_BF16) LAUNCH(128, true); else LAUNCH(128, false); }
+#undef LAUNCH
+  return launch_status();
+}
+
 // K smoothing + quantization as one call: km = mean over the sequence (sage_k_mean) and the INT8 quantization of k - km
 // (sage_quant_qk_int8 with is_key = 1, blk 64).  Two launches at every length: the sequence is cut into at most 16 chunks
 // (kmean_chunk_rows) and the quantizer finishes the mean itself; bit-identical to the two separate entry points.
@@ -551,8 +727,11 @@ extern "C" int sage_k_smooth_quant(const sage_tensor* k, int dtype, int B, int H
   else { if (dtype == SAGE_BF16) LAUNCH(128, true); else LAUNCH(128, false); }
 #undef LAUNCH
   if (launch_status() != SAGE_OK) return SAGE_ERR_LAUNCH;
-  return quant_impl(k, dtype, B, H, N, D, nullptr, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream, nullptr,
-                    0, nullptr, ws, S, km);
+  QuantParams p;
+  const int st0 = quant_impl(k, dtype, B, H, N, D, nullptr, out, scale, gran, 1, 64, 64, 1.0f, rounding, nullptr, 1, nullptr, stream,
+                             nullptr, 0, nullptr, ws, S, km, &p);
+  if (st0 != SAGE_OK) return st0;
+  return launch_k_quant(p, dtype, B, H, N, D, st);
 }
 
 extern "C" size_t sage_kv_prepare_fp8_workspace_bytes(int B, int H, int N, int D) {
@@ -592,7 +771,11 @@ extern "C" int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, i
 #define LA(DD, BF)                                                                                                          \
   hipLaunchKernelGGL((kv_partial_kernel<DD, BF>), ga, dim3(256), 0, st, kp, k->stride_b, k->stride_h, k->stride_n, q.v, q.sb, \
                      q.sh, q.sn, N, kpart, vpart, S)
-#define LB(DD, BF) hipLaunchKernelGGL((kv_quant_kernel<DD, BF>), gb, dim3(256), 0, st, p, q, nblk_k)
+#define LB(DD, BF)                                                                                                      \
+  do {                                                                                                                  \
+    if (rounding == SAGE_ROUND_TRITON) hipLaunchKernelGGL((kv_quant_kernel<DD, BF, true>), gb, dim3(256), 0, st, p, q, nblk_k);  \
+    else hipLaunchKernelGGL((kv_quant_kernel<DD, BF, false>), gb, dim3(256), 0, st, p, q, nblk_k);                      \
+  } while (0)
   const bool bf = dtype == SAGE_BF16;
   if (D == 64) { if (bf) LA(64, true); else LA(64, false); } else { if (bf) LA(128, true); else LA(128, false); }
   if (launch_status() != SAGE_OK) return SAGE_ERR_LAUNCH;
