@@ -25,15 +25,27 @@ __global__ __launch_bounds__(256) void v_stats_partial_kernel(const uint16_t* __
   float mx[8], mn[8], sm[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { mx[j] = -1000000.0f; mn[j] = 1000000.0f; sm[j] = 0.f; }  // fused.cu:345-347
-#pragma unroll 4
-  for (int i = 0; i < VQ_ROWS / RPP; ++i) {
-    const int row = s * VQ_ROWS + i * RPP + tr;
-    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tokens in [N, ceil16(N)) count as zeros (fused.cu:335)
-    const int n16 = (N + 15) / 16 * 16;
-    if (row < n16) {
-      if (row < N) unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
+  if ((s + 1) * VQ_ROWS <= N) {
+    // whole chunk: unconditional loads, eight in flight (hipcc sinks a conditional load into its branch and waits for it
+    // before the next one is issued: see k_mean_partial_body); same operations in the same order
+#pragma unroll 8
+    for (int i = 0; i < VQ_ROWS / RPP; ++i) {
+      float f[8];
+      unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)(s * VQ_ROWS + i * RPP + tr) * sn), f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { mx[j] = fmaxf(mx[j], f[j]); mn[j] = fminf(mn[j], f[j]); sm[j] += f[j]; }
+    }
+  } else {
+#pragma unroll 4
+    for (int i = 0; i < VQ_ROWS / RPP; ++i) {
+      const int row = s * VQ_ROWS + i * RPP + tr;
+      float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tokens in [N, ceil16(N)) count as zeros (fused.cu:335)
+      const int n16 = (N + 15) / 16 * 16;
+      if (row < n16) {
+        if (row < N) unpack8<BF16>(*reinterpret_cast<const uint4*>(base + (int64_t)row * sn), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mx[j] = fmaxf(mx[j], f[j]); mn[j] = fminf(mn[j], f[j]); sm[j] += f[j]; }
+      }
     }
   }
   __shared__ float red[3][RPP][D + 1];

@@ -37,11 +37,17 @@ __device__ __forceinline__ void v_quant_transpose_body(const uint16_t* __restric
   const int bi = tg / 16, t0 = 4 * (tg % 16);
   const int blk = bx * BLKS + bi;
   float x[4][8];
+  // the four loads are unconditional (row clamped) and issued together: under `if (row < N)` hipcc sinks each into its
+  // branch and waits for it before the next one (four dependent round trips per thread)
+  uint4 raw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    raw[i] = *reinterpret_cast<const uint4*>(v + b * sb + h * sh + (int64_t)min(blk * 64 + t0 + i, N - 1) * sn + tc * 8);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = blk * 64 + t0 + i;
-    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < N) unpack8<BF16>(*reinterpret_cast<const uint4*>(v + b * sb + h * sh + (int64_t)row * sn + tc * 8), f);
+    float f[8];
+    unpack8<BF16>(raw[i], f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[i][j] = row < N ? (f[j] - mean[j]) * rcp[j] : 0.f;  // pad columns are exact zeros
   }

@@ -40,7 +40,8 @@ struct MergeMany {
   const float* lse[SAGE_MERGE_MAX];
   int count;
 };
-template <bool BF16>
+// MAXC: compile-time bound of `count` (2, 4, 8 or 16): the slots are unrolled
+template <bool BF16, int MAXC>
 __global__ __launch_bounds__(256) void merge_many_kernel(const MergeMany m, uint16_t* __restrict__ o_out,
                                                          float* __restrict__ lse_out, int64_t rows, int D,
                                                          const float in_mult, const float* __restrict__ corr,
@@ -50,19 +51,32 @@ __global__ __launch_bounds__(256) void merge_many_kernel(const MergeMany m, uint
   const int64_t row = gid / tpr;
   const int c = (int)(gid % tpr);
   if (row >= rows) return;
+  // every lse and every o row of this thread is requested up front (slots unrolled; a slot past `count` repeats the last
+  // one and is not used): as a run-time loop with the o load under `if (l != -inf)` each block cost two dependent round
+  // trips -- hipcc sinks a load into the branch that uses it.  The uses below are selects, not branches, for that reason.
+  // The combination runs in slot order as before: deterministic, bit-identical.
+  float l[MAXC];
+  uint4 raw[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int s = i < m.count ? i : m.count - 1;
+    l[i] = m.lse[s][row] * in_mult;
+    raw[i] = *reinterpret_cast<const uint4*>(m.o[s] + row * D + c * 8);
+  }
   float mx = -INFINITY;
-  for (int i = 0; i < m.count; ++i) mx = fmaxf(mx, m.lse[i][row] * in_mult);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) mx = i < m.count ? fmaxf(mx, l[i]) : mx;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float sum = 0.f;
-  for (int i = 0; i < m.count; ++i) {  // fixed order: deterministic
-    const float l = m.lse[i][row] * in_mult;
-    if (l == -INFINITY) continue;       // empty block (e.g. fully masked): weight 0, its o may be anything
-    const float w = __expf(l - mx);
-    sum += w;
-    float f[8];
-    unpack8<BF16>(*reinterpret_cast<const uint4*>(m.o[i] + row * D + c * 8), f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += f[j] * w;
+  for (int i = 0; i < MAXC; ++i) {  // fixed order: deterministic
+    const bool use = i < m.count && l[i] != -INFINITY;  // empty block (e.g. fully masked): weight 0, its o may be anything
+    const float w = __expf(l[i] - mx);
+    sum = use ? sum + w : sum;
+    float f[8];
+    unpack8<BF16>(raw[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = use ? acc[j] + f[j] * w : acc[j];
   }
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
   uint32_t w[4];
@@ -134,12 +148,16 @@ extern "C" int sage_merge_attn_states_multi_ex(const void* const* o_blks, const 
   const int64_t threads = rows * (D / 8);
   const dim3 grid((unsigned)((threads + 255) / 256));
   launch_begin();
-  if (o_dtype == SAGE_BF16)
-    hipLaunchKernelGGL((merge_many_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D,
-                       lse_in_mult, corr, corr_mult);
-  else
-    hipLaunchKernelGGL((merge_many_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D,
-                       lse_in_mult, corr, corr_mult);
+#define LAUNCH(BF, MC)                                                                                                  \
+  hipLaunchKernelGGL((merge_many_kernel<BF, MC>), grid, dim3(256), 0, (hipStream_t)stream, m, (uint16_t*)o_out, lse_out, rows, D, \
+                     lse_in_mult, corr, corr_mult)
+#define BY_COUNT(BF)                                                                                                    \
+  do {                                                                                                                  \
+    if (count <= 2) LAUNCH(BF, 2); else if (count <= 4) LAUNCH(BF, 4); else if (count <= 8) LAUNCH(BF, 8); else LAUNCH(BF, 16); \
+  } while (0)
+  if (o_dtype == SAGE_BF16) BY_COUNT(true); else BY_COUNT(false);
+#undef BY_COUNT
+#undef LAUNCH
   return launch_status();
 }
 
