@@ -136,28 +136,32 @@ void attn_i8_kernel(const AttnParams p) {
       raw[ks][0] = *reinterpret_cast<const uint4*>(qp + 32 * ks);
       raw[ks][1] = *reinterpret_cast<const uint4*>(qp + 32 * ks + 8);
     }
-    auto unpack = [&](const uint4& u, float (&f)[8]) __attribute__((always_inline)) {
-      if (p.q_bf16) unpack8<true>(u, f); else unpack8<false>(u, f);
-      if (!valid) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = 0.f;
-      }
-    };
-    float amax = 0.f, dot = 0.f;
-    // (the row dot q . k_mean is the LSE correction: only computed when the caller asked for the LSE)
+    // (the LSE correction q . k_mean is only computed when the caller asked for the LSE)
     const uint16_t* kmp = (p.km && p.lse) ? p.km + ((int64_t)b * p.Hk + hk) * D + 16 * hh : nullptr;
+    // Everything below is instantiated per element type (ONE uniform branch here instead of one per 8-element chunk) and
+    // the numerics flavour is the kernel's KTHREAD (per-thread Q scales <=> the Triton quantizer's numerics, run_attn): with
+    // both as run-time flags inside the unrolled loops hipcc emitted two scalar branches per ELEMENT -- ~500 scalar
+    // instructions and as many taken branches per wave, a third of a short sequence's fixed cost.
+    auto fused_q = [&](auto bf16_tag) __attribute__((always_inline)) {
+    constexpr bool QBF = decltype(bf16_tag)::value;
+    constexpr bool triton = KTHREAD;
+    if (!valid) {  // rows >= M are zeros (as in K1): zeroed once here, 4 selects per chunk instead of 8 per pass
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) raw[ks][0] = raw[ks][1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    float amax = 0.f, dot = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float f[8];
-        unpack(raw[ks][c], f);
+        unpack8<QBF>(raw[ks][c], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
         if (kmp) {
           float g[8];
           const uint4 uk = *reinterpret_cast<const uint4*>(kmp + 32 * ks + 8 * c);
-          if (p.q_bf16) unpack8<true>(uk, g); else unpack8<false>(uk, g);
+          unpack8<QBF>(uk, g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) dot += f[e] * g[e];
         }
@@ -167,8 +171,7 @@ void attn_i8_kernel(const AttnParams p) {
     // lives through the whole tile loop costs the head_dim-64 FP8 variants their third wave per SIMD)
     const float lse_corr = swap_sum(dot);
     if (p.lse && hh == 0 && valid) p.lse[((int64_t)b * p.Hq + h) * M_ + row] = lse_corr;
-    const bool triton = p.qgran == SAGE_GRAN_PER_THREAD;
-    if (triton) {  // rows with equal r % 8 inside the 32-row block (quant_per_thread.py:27-36)
+    if constexpr (triton) {  // rows with equal r % 8 inside the 32-row block (quant_per_thread.py:27-36)
       amax = fmaxf(amax, __shfl_xor(amax, 8));
       amax = fmaxf(amax, __shfl_xor(amax, 16));
     } else {       // per warp: warpq rows (16 or 32) share a scale (fused.cu:746-750)
@@ -185,41 +188,39 @@ void attn_i8_kernel(const AttnParams p) {
     // division decides, for that chunk: ~6 % of the chunks; deciding once for the wave's whole 32 x D block sent
     // 40 % of the waves through the slow form)
     const bool rcp_bad = !(fabsf(rcp_sc) < 3.0e38f);
-    auto quant8 = [&](const float (&f)[8], int (&qv)[8], const bool exact) __attribute__((always_inline)) -> bool {
-      bool near = false;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (triton) {
-          if (exact) {
-            float y = f[e] / sc;  // IEEE division (quant_per_thread.py:41)
-            y = y + (y >= 0.f ? 0.5f : -0.5f);
-            qv[e] = (int)y;
-          } else {
-            qv[e] = round_half_away_fast(f[e] * rcp_sc, near);
-          }
-        } else {
-          qv[e] = (int)rintf(f[e] * inv);  // cvt.rni (fused.cu:176-181)
-        }
-        qv[e] = min(max(qv[e], -128), 127);
-      }
-      return near;
-    };
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint32_t w[4];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float f[8];
-        unpack(raw[ks][c], f);
+        unpack8<QBF>(raw[ks][c], f);
         int qv[8];
-        const bool near = quant8(f, qv, false);
-        if (__builtin_amdgcn_ballot_w64(triton && (near || rcp_bad)) != 0) (void)quant8(f, qv, true);
+        // (no clamp on the two fast forms: |f| <= amax, so |f * r| <= 127 (1 + 3 ulp) and rint() of it is at most 127; as K1)
+        if constexpr (triton) {
+          bool near = false;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qv[e] = round_half_away_fast(f[e] * rcp_sc, near);
+          if (__builtin_amdgcn_ballot_w64(near || rcp_bad) != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float y = f[e] / sc;  // IEEE division (quant_per_thread.py:41)
+              y = y + (y >= 0.f ? 0.5f : -0.5f);
+              qv[e] = min(max((int)y, -128), 127);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qv[e] = (int)rintf(f[e] * inv);  // cvt.rni (fused.cu:176-181)
+        }
         w[2 * c] = pack_i8x4(qv[0], qv[1], qv[2], qv[3]);
         w[2 * c + 1] = pack_i8x4(qv[4], qv[5], qv[6], qv[7]);
       }
       qf[ks][0] = (int)w[0]; qf[ks][1] = (int)w[1]; qf[ks][2] = (int)w[2]; qf[ks][3] = (int)w[3];
     }
     qsc = sc * p.logit_mult;
+    };
+    if (p.q_bf16) fused_q(std::true_type{}); else fused_q(std::false_type{});
   }
   };
   const float* ksp = p.k_scale + b * p.ks_b + hk * p.ks_h;
@@ -1127,7 +1128,10 @@ void attn_i8_kernel(const AttnParams p) {
     // A lane holds runs of 4 output channels (8 B); lane ^ 32 holds the neighbouring run of the same row.  The two halves
     // exchange words (v_permlane32_swap) so that each stores 16 contiguous bytes: 8 global_store_dwordx4 per lane instead
     // of 16 dwordx2 (the store tail of a workgroup is bound by the number of store instructions, not by bytes).
-    auto store_rows = [&](auto has_vm) __attribute__((always_inline)) {
+    // (instantiated per output element type and store form, selected by ONE uniform branch: as run-time flags inside the
+    //  unrolled loops they cost a scalar branch per 4-channel run)
+    auto store_rows = [&](auto has_vm, auto obf_tag, auto vec16_tag) __attribute__((always_inline)) {
+      constexpr bool OBF = decltype(obf_tag)::value, VEC16 = decltype(vec16_tag)::value;
       const float* vmp = p.v_mean + ((int64_t)b * p.Hk + hk) * D;
       auto run4 = [&](const int dt, const int g4) __attribute__((always_inline)) -> uint2 {
         const int d0 = 32 * dt + 8 * g4 + 4 * hh_l;
@@ -1142,14 +1146,14 @@ void attn_i8_kernel(const AttnParams p) {
           const float4 vmv = *reinterpret_cast<const float4*>(vmp + d0);
           x[0] += vmv.x; x[1] += vmv.y; x[2] += vmv.z; x[3] += vmv.w;
         }
+        // o = round16(round32(acc * inv ...)): the fp32 value is made opaque, otherwise hipcc folds the last multiply and the
+        // convert into v_fma_mixlo_f16 (one rounding) in SOME instantiations -- more exact by up to one fp16 ulp in ~5e-5 of
+        // the elements, but not the arithmetic of the reference epilogue (…sm80.cu:600-640) nor of this library's earlier builds
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(x[e]));
         uint2 w;
-        if (p.out_bf16) {
-          w.x = (uint32_t)f32_to_elem_bits<true>(x[0]) | ((uint32_t)f32_to_elem_bits<true>(x[1]) << 16);
-          w.y = (uint32_t)f32_to_elem_bits<true>(x[2]) | ((uint32_t)f32_to_elem_bits<true>(x[3]) << 16);
-        } else {
-          w.x = (uint32_t)f32_to_elem_bits<false>(x[0]) | ((uint32_t)f32_to_elem_bits<false>(x[1]) << 16);
-          w.y = (uint32_t)f32_to_elem_bits<false>(x[2]) | ((uint32_t)f32_to_elem_bits<false>(x[3]) << 16);
-        }
+        w.x = (uint32_t)f32_to_elem_bits<OBF>(x[0]) | ((uint32_t)f32_to_elem_bits<OBF>(x[1]) << 16);
+        w.y = (uint32_t)f32_to_elem_bits<OBF>(x[2]) | ((uint32_t)f32_to_elem_bits<OBF>(x[3]) << 16);
         return w;
       };
 #pragma unroll
@@ -1158,7 +1162,7 @@ void attn_i8_kernel(const AttnParams p) {
         for (int gp = 0; gp < 2; ++gp) {
           // runs A (g4 = 2gp) and B (g4 = 2gp+1): the low half-wave keeps both halves of A, the high one both halves of B
           const uint2 wa = run4(dt, 2 * gp), wb = run4(dt, 2 * gp + 1);
-          if (p.o_vec16) {  // (a row and its lane ^ 32 twin are both inside or both outside the `row < M` guard)
+          if constexpr (VEC16) {  // (a row and its lane ^ 32 twin are both inside or both outside the `row < M` guard)
             const auto sx = __builtin_amdgcn_permlane32_swap(wa.x, wb.x, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(wa.y, wb.y, false, false);
             *reinterpret_cast<uint4*>(op + 32 * dt + 16 * gp + 8 * hh_l) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
@@ -1168,7 +1172,16 @@ void attn_i8_kernel(const AttnParams p) {
           }
         }
     };
-    if (p.v_mean) store_rows(std::true_type{}); else store_rows(std::false_type{});
+    constexpr std::true_type kT{};
+    constexpr std::false_type kF{};
+    if (!p.v_mean && p.o_vec16) {  // the common forms
+      if (p.out_bf16) store_rows(kF, kT, kT); else store_rows(kF, kF, kT);
+    } else if (p.v_mean) {
+      if (p.o_vec16) { if (p.out_bf16) store_rows(kT, kT, kT); else store_rows(kT, kF, kT); }
+      else { if (p.out_bf16) store_rows(kT, kT, kF); else store_rows(kT, kF, kF); }
+    } else {
+      if (p.out_bf16) store_rows(kF, kT, kF); else store_rows(kF, kF, kF);
+    }
     if (p.lse && hh_l == 0) {
       const float lse2 = m_run + log2f(l_tot) - kPOff;  // base 2, scaled + smoothed logits (…sm80.cu:657-668)
       float* const slot = p.lse + ((int64_t)b * p.Hq + h) * M_ + row_l;
