@@ -714,7 +714,9 @@ void attn_i8_kernel(const AttnParams p) {
   // S(0) from a mix of K(0) and K(2) rows -- one wrong 32-row wave, the same wrong value every time.
   if constexpr (!abl::kNoPrologueBarrier) __syncthreads();
   tile_scales(0, sc0, sc1);
-  mask_limit(0, s_cur);
+  // a plain tile 0 needs no mask (64 compare + select instructions per wave); the causal head_dim-64 variants keep it
+  // unconditional -- under the branch they need 170 registers, two over the three-waves-per-SIMD line
+  if (CAUSAL || n_plain <= 0) mask_limit(0, s_cur);
   mx_cur = row_max(s_cur, sc0, sc1);
 
   // fast loop, unrolled by two so that S(j) / S(j+1) swap roles without register copies
@@ -1151,9 +1153,14 @@ void attn_i8_kernel(const AttnParams p) {
         // the elements, but not the arithmetic of the reference epilogue (…sm80.cu:600-640) nor of this library's earlier builds
 #pragma unroll
         for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(x[e]));
-        uint2 w;
-        w.x = (uint32_t)f32_to_elem_bits<OBF>(x[0]) | ((uint32_t)f32_to_elem_bits<OBF>(x[1]) << 16);
-        w.y = (uint32_t)f32_to_elem_bits<OBF>(x[2]) | ((uint32_t)f32_to_elem_bits<OBF>(x[3]) << 16);
+        uint2 w;  // packed converts (round to nearest even, as the scalar ones): v_cvt_pk_{f16,bf16}_f32
+        if constexpr (OBF) {
+          w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2f){x[0], x[1]}, v2bf));
+          w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2f){x[2], x[3]}, v2bf));
+        } else {
+          w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2f){x[0], x[1]}, v2h));
+          w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2f){x[2], x[3]}, v2h));
+        }
         return w;
       };
 #pragma unroll
