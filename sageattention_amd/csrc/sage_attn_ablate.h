@@ -47,6 +47,16 @@ SAGE_ABL_FLAG(kNoLdsV, true);
 #else
 SAGE_ABL_FLAG(kNoLdsV, false);
 #endif
+#ifdef SAGE_ABL_HALFLDS    // fp16 stream: every second K / V^T fragment read and every second tile copy dropped -- what a wave
+SAGE_ABL_FLAG(kHalfLds, true);   // with TWO 32-row sub-tiles (fragments shared) would save per row, at today's occupancy
+#else
+SAGE_ABL_FLAG(kHalfLds, false);
+#endif
+#ifdef SAGE_ABL_CONSTODD   // control of HALFLDS: every fragment is still READ and every tile copied, but every second MFMA is fed a
+SAGE_ABL_FLAG(kConstOdd, true);  // constant register instead (the share of HALFLDS's gain that is operand-toggle power, not LDS)
+#else
+SAGE_ABL_FLAG(kConstOdd, false);
+#endif
 #ifdef SAGE_ABL_NOROWSUM_F8 // FP8 stream: 8 instead of 32 row-sum adds per tile (what the adds cost: C4 +4 %, D=64 8K +7 %)
 SAGE_ABL_FLAG(kNoRowSumF8, true);
 #else
