@@ -26,23 +26,33 @@ struct VQuantGeom {
 // 0.24 ms at C4 against 0.16 now).  Rows of the image are 64 B; every group of 8 rows is padded by 16 B, which spreads
 // the 16 channel groups of a wave over 8 banks (2-way is free for ds_write_b32) and keeps the 16-B reads aligned.
 // `mean` / `rcp`: the thread's 8 channels (tc*8 ..); `bx` = workgroup index along the sequence; `tile` = BLKS*IMG dwords.
-template <int D, bool BF16>
-__device__ __forceinline__ void v_quant_transpose_body(const uint16_t* __restrict__ v, int64_t sb, int64_t sh, int64_t sn,
-                                                       int N, const float (&mean)[8], const float (&rcp)[8],
-                                                       uint8_t* __restrict__ out, int64_t ob, int64_t oh, int64_t od,
-                                                       int64_t o_tile, int bx, int h, int b, uint32_t* __restrict__ tile) {
+// The body in three steps (the streaming K/V pre-pass of sage_quant.hip runs them in a loop over several units, with the next
+// unit's rows requested while this one is transposed); `bx` = unit index along the sequence (BLKS x 64 tokens).
+// step 1: the thread's four token rows (clamped to the last row: the loads are unconditional and issued together -- under
+// `if (row < N)` hipcc sinks each into its branch and waits for it before the next one, four dependent round trips per thread)
+template <int D>
+__device__ __forceinline__ void v_quant_load(const uint16_t* __restrict__ vhead, int64_t sn, int N, int bx, uint4 (&raw)[4]) {
   using G = VQuantGeom<D>;
-  constexpr int TPR = G::TPR, BLKS = G::BLKS, IMG = G::IMG;
-  const int tg = threadIdx.x / TPR, tc = threadIdx.x % TPR;
-  const int bi = tg / 16, t0 = 4 * (tg % 16);
-  const int blk = bx * BLKS + bi;
-  float x[4][8];
-  // the four loads are unconditional (row clamped) and issued together: under `if (row < N)` hipcc sinks each into its
-  // branch and waits for it before the next one (four dependent round trips per thread)
-  uint4 raw[4];
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (opaque per unit: keeps a loop around this from hoisting every address term into registers)
+  const int tg = tid / G::TPR, tc = tid % G::TPR;
+  const int row0 = (bx * G::BLKS + tg / 16) * 64 + 4 * (tg % 16);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    raw[i] = *reinterpret_cast<const uint4*>(v + b * sb + h * sh + (int64_t)min(blk * 64 + t0 + i, N - 1) * sn + tc * 8);
+  for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const uint4*>(vhead + (int64_t)min(row0 + i, N - 1) * sn + tc * 8);
+}
+
+// step 2: scale, round to e4m3, write the thread's 8 dwords of the [d][pos] image (tile: BLKS * IMG dwords)
+template <int D, bool BF16>
+__device__ __forceinline__ void v_quant_to_image(const uint4 (&raw)[4], int N, int bx, const float (&mean)[8], const float (&rcp)[8],
+                                                 uint32_t* __restrict__ tile) {
+  using G = VQuantGeom<D>;
+  constexpr int TPR = G::TPR, IMG = G::IMG;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int tg = tid / TPR, tc = tid % TPR;
+  const int bi = tg / 16, t0 = 4 * (tg % 16);
+  const int blk = bx * G::BLKS + bi;
+  float x[4][8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = blk * 64 + t0 + i;
@@ -61,8 +71,14 @@ __device__ __forceinline__ void v_quant_transpose_body(const uint16_t* __restric
     const int d = tc * 8 + j;
     tile[bi * IMG + d * 16 + 4 * (d >> 3) + pos_dw] = (uint32_t)pk;
   }
-  __syncthreads();
-  // D rows x 64 B per block: 4 x 16 B chunks per row
+}
+
+// step 3 (behind a barrier): D rows x 64 B per block out of the image: 4 x 16 B chunks per row
+template <int D>
+__device__ __forceinline__ void v_quant_store_image(uint8_t* __restrict__ out, int64_t ob, int64_t oh, int64_t od, int64_t o_tile,
+                                                    int N, int bx, int h, int b, const uint32_t* __restrict__ tile) {
+  using G = VQuantGeom<D>;
+  constexpr int BLKS = G::BLKS, IMG = G::IMG;
   for (int c = threadIdx.x; c < BLKS * D * 4; c += 256) {
     const int bo = c / (D * 4), cc = c % (D * 4), d = cc >> 2, ch = cc & 3;
     const int ob_blk = bx * BLKS + bo;
@@ -70,6 +86,18 @@ __device__ __forceinline__ void v_quant_transpose_body(const uint16_t* __restric
     const uint4 u = *reinterpret_cast<const uint4*>(&tile[bo * IMG + d * 16 + 4 * (d >> 3) + ch * 4]);
     *reinterpret_cast<uint4*>(out + b * ob + h * oh + (int64_t)d * od + ob_blk * o_tile + ch * 16) = u;
   }
+}
+
+template <int D, bool BF16>
+__device__ __forceinline__ void v_quant_transpose_body(const uint16_t* __restrict__ v, int64_t sb, int64_t sh, int64_t sn,
+                                                       int N, const float (&mean)[8], const float (&rcp)[8],
+                                                       uint8_t* __restrict__ out, int64_t ob, int64_t oh, int64_t od,
+                                                       int64_t o_tile, int bx, int h, int b, uint32_t* __restrict__ tile) {
+  uint4 raw[4];
+  v_quant_load<D>(v + b * sb + h * sh, sn, N, bx, raw);
+  v_quant_to_image<D, BF16>(raw, N, bx, mean, rcp, tile);
+  __syncthreads();
+  v_quant_store_image<D>(out, ob, oh, od, o_tile, N, bx, h, b, tile);
 }
 
 }  // namespace sage

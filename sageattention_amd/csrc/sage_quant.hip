@@ -10,6 +10,10 @@
 #include "sage_common.h"
 #include "sage_fp8_kernels.h"
 
+#ifndef SAGE_KV_UNITS_CAP  // blocks / units one workgroup of the streaming K + V quantizer walks at most (variant builds sweep it)
+#define SAGE_KV_UNITS_CAP 32
+#endif
+
 namespace sage {
 
 // ------------------------------------------------------------------------------------------------
@@ -388,20 +392,18 @@ __global__ __launch_bounds__(256, BLK * D <= 64 * 128 ? 7 : 4) void quant_qk_int
 // its barrier, zeroes buffer (i + 2) % 3 -- last read by block i-1, whose readers have all passed this barrier, and next
 // written by block i+2, behind the barrier of block i+1).
 template <int D, bool BF16, bool TRITON>
-__global__ __launch_bounds__(256, D == 64 ? 5 : 4) void k_quant_stream_kernel(const QuantParams p, const int per_wg) {
+__device__ __forceinline__ void k_quant_stream_body(const QuantParams& p, const int per_wg, const int wg, const int h, const int b,
+                                                    const int H, unsigned int (*gmax)[64], float (*mpart)[D]) {
   constexpr int BLK = 64;
   using G = QuantGeom<D, BLK>;
-  __shared__ unsigned int gmax[3][64];
-  __shared__ __attribute__((aligned(16))) float mpart[16][D];
-  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int nblk = (p.N + BLK - 1) / BLK;
-  const int blk0 = blockIdx.x * per_wg, blk1 = min(blk0 + per_wg, nblk);  // the host launches no empty workgroup
+  const int blk0 = wg * per_wg, blk1 = min(blk0 + per_wg, nblk);  // the host launches no empty workgroup
   if (threadIdx.x < 192) (&gmax[0][0])[threadIdx.x] = 0u;
   const uint16_t* xbase = p.x + b * p.xsb + h * p.xsh + (threadIdx.x % G::TPR) * 8;
   const int64_t o_boff = b * p.osb;
   uint4 raw[G::NP];
   quant_load_rows<D, BLK>(xbase, p.xsn, blk0, p.N, raw);
-  const uint4 mbits = quant_mean_bits<D, BF16>(p, h, b, H, blockIdx.x == 0, mpart);
+  const uint4 mbits = quant_mean_bits<D, BF16>(p, h, b, H, wg == 0, mpart);
   int par = 0;
   for (int blk = blk0; blk < blk1; ++blk) {
     // the rows of the next block are requested as soon as this block's are unpacked (their registers are free then) and
@@ -411,6 +413,13 @@ __global__ __launch_bounds__(256, D == 64 ? 5 : 4) void k_quant_stream_kernel(co
     });
     par = par == 2 ? 0 : par + 1;
   }
+}
+
+template <int D, bool BF16, bool TRITON>
+__global__ __launch_bounds__(256, D == 64 ? 5 : 4) void k_quant_stream_kernel(const QuantParams p, const int per_wg) {
+  __shared__ unsigned int gmax[3][64];
+  __shared__ __attribute__((aligned(16))) float mpart[16][D];
+  k_quant_stream_body<D, BF16, TRITON>(p, per_wg, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gmax, mpart);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -518,6 +527,68 @@ __global__ __launch_bounds__(256, D == 64 ? 8 : 7) void kv_quant_kernel(const Qu
     *reinterpret_cast<float4*>(o + 4) = make_float4(vs[4], vs[5], vs[6], vs[7]);
   }
   v_quant_transpose_body<D, BF16>(q.v, q.sb, q.sh, q.sn, p.N, mean, rcp, q.out, q.ob, q.oh, q.od, q.o_tile, bx, h, b, tile);
+}
+
+// Launch B as a STREAMING kernel for long sequences (round 3; sage_kv_prepare_fp8 picks by the units a workgroup would walk): workgroups [0, nwg_k) walk per_k consecutive K blocks
+// of their head (k_quant_stream_body), the others per_v consecutive V units (BLKS x 64 tokens), the next unit's rows
+// requested while this one is transposed, the image double-buffered in LDS (one barrier per unit), and the per-channel
+// scale -- S maxima and two IEEE divisions per channel -- finished ONCE per workgroup by its first token group instead of by
+// every thread for every unit (that was three quarters of the V half's vector work).  Same arithmetic: bit-identical.
+template <int D, bool BF16, bool TRITON>
+__global__ __launch_bounds__(256, D == 64 ? 5 : 4) void kv_quant_stream_kernel(const QuantParams p, const VPrepParams q, const int per_k,
+                                                                               const int nwg_k, const int per_v) {
+  using G = VQuantGeom<D>;
+  __shared__ unsigned int gmax[3][64];
+  __shared__ __attribute__((aligned(16))) float exch[16][D];  // chunk partials of this head: K sums or V max|v|
+  __shared__ __attribute__((aligned(16))) uint32_t tile[2][G::BLKS * G::IMG];
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  if ((int)blockIdx.x < nwg_k) {
+    k_quant_stream_body<D, BF16, TRITON>(p, per_k, blockIdx.x, h, b, H, gmax, exch);
+    return;
+  }
+  const int wg = blockIdx.x - nwg_k;
+  const int nunits = ((p.N + 63) / 64 + G::BLKS - 1) / G::BLKS;
+  const int u0 = wg * per_v, u1 = min(u0 + per_v, nunits);
+  const uint16_t* vhead = q.v + b * q.sb + h * q.sh;
+  uint4 raw[4];
+  v_quant_load<D>(vhead, q.sn, p.N, u0, raw);
+  const int tg = threadIdx.x / G::TPR, tc = threadIdx.x % G::TPR;
+  if (tg < p.S) {  // one round trip for all chunks (S <= 16 <= token groups per workgroup)
+    const float* pp = q.part + (((int64_t)b * H + h) * p.S + tg) * D + tc * 8;
+    *reinterpret_cast<float4*>(&exch[tg][tc * 8]) = *reinterpret_cast<const float4*>(pp);
+    *reinterpret_cast<float4*>(&exch[tg][tc * 8 + 4]) = *reinterpret_cast<const float4*>(pp + 4);
+  }
+  __syncthreads();
+  if (tg == 0) {  // (this thread alone reads columns tc*8 .. tc*8+7 of exch, so it may overwrite them in rows 0 and 1)
+    float rc[8], vs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = exch[0][tc * 8 + j];
+      for (int s_ = 1; s_ < p.S; ++s_) a = fmaxf(a, exch[s_][tc * 8 + j]);
+      rc[j] = q.scale_max / a;   // v_stats_final_kernel
+      vs[j] = a / q.scale_max;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { exch[0][tc * 8 + j] = rc[j]; exch[1][tc * 8 + j] = vs[j]; }
+    if (wg == 0) {
+      float* o = q.v_scale + ((int64_t)b * H + h) * D + tc * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(vs[4], vs[5], vs[6], vs[7]);
+    }
+  }
+  __syncthreads();
+  float mean[8], rcp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mean[j] = 0.f; rcp[j] = exch[0][tc * 8 + j]; }
+  for (int u = u0; u < u1; ++u) {
+    uint32_t* img = tile[(u - u0) & 1];
+    v_quant_to_image<D, BF16>(raw, p.N, u, mean, rcp, img);
+    if (u + 1 < u1) v_quant_load<D>(vhead, q.sn, p.N, u + 1, raw);
+    // one barrier per unit: the image buffers alternate, and the readers of this unit's buffer two units ago all passed the
+    // previous unit's barrier before anyone writes it again
+    __syncthreads();
+    v_quant_store_image<D>(q.out, q.ob, q.oh, q.od, q.o_tile, p.N, u, h, b, img);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -762,19 +833,36 @@ extern "C" int sage_kv_prepare_fp8(const sage_tensor* k, const sage_tensor* v, i
   q.out = (uint8_t*)v_fp8->data; q.ob = v_fp8->stride_b; q.oh = v_fp8->stride_h; q.od = v_fp8->stride_n; q.o_tile = 64;
   q.v_scale = v_scale; q.part = vpart; q.scale_max = scale_max;
   const int nblk_k = (N + 63) / 64;
-  const int vq_blks = D == 128 ? 1 : 2;  // 64-token blocks per V workgroup (VQuantGeom<D>::BLKS)
-  const int nblk_v = (nblk_k + vq_blks - 1) / vq_blks;
+  const int vq_blks = D == 128 ? 1 : 2;  // 64-token blocks per V unit (VQuantGeom<D>::BLKS)
+  const int nunit_v = (nblk_k + vq_blks - 1) / vq_blks;
+  // K blocks / V units per workgroup: each half gets about half of the workgroups the chip holds at once (k_quant_blocks_per_wg)
+  const int64_t target = 128 * (D == 64 ? 5 : 4);
+  // (at most SAGE_KV_UNITS_CAP units per workgroup: beyond, more generations of workgroups measured better than longer walks)
+  auto per_wg = [&](int units) { int64_t per = ((int64_t)B * H * units + target - 1) / target; per = per > SAGE_KV_UNITS_CAP ? SAGE_KV_UNITS_CAP : per; return (int)(per < 1 ? 1 : per > units ? units : per); };
+  const int per_k = per_wg(nblk_k), per_v = per_wg(nunit_v);
+  const int nwg_k = (nblk_k + per_k - 1) / per_k, nwg_v = (nunit_v + per_v - 1) / per_v;
   hipStream_t st = (hipStream_t)stream;
   launch_begin();
-  const dim3 ga(2 * S, H, B), gb(nblk_k + nblk_v, H, B);
+  const dim3 ga(2 * S, H, B), gb(nwg_k + nwg_v, H, B);
   const uint16_t* kp = (const uint16_t*)k->data;
 #define LA(DD, BF)                                                                                                          \
   hipLaunchKernelGGL((kv_partial_kernel<DD, BF>), ga, dim3(256), 0, st, kp, k->stride_b, k->stride_h, k->stride_n, q.v, q.sb, \
                      q.sh, q.sn, N, kpart, vpart, S)
+  // Streaming pays where a workgroup walks enough units to hide its start-up (measured, tools/prepass_ab.py, B*H = 128: head_dim
+  // 128: 4-8 units per workgroup +6..10 % slower than one unit per workgroup, 16-32 units 6-12 % faster, 64 even; head_dim 64:
+  // 2 units slower, 4 faster); below that the one-unit-per-workgroup kernel (seven or eight workgroups per CU) runs.
+  const bool stream_b = per_v >= (D == 64 ? 4 : 12);
+  const int nblk_v1 = nunit_v;
+  const dim3 gb1(nblk_k + nblk_v1, H, B);
 #define LB(DD, BF)                                                                                                      \
   do {                                                                                                                  \
-    if (rounding == SAGE_ROUND_TRITON) hipLaunchKernelGGL((kv_quant_kernel<DD, BF, true>), gb, dim3(256), 0, st, p, q, nblk_k);  \
-    else hipLaunchKernelGGL((kv_quant_kernel<DD, BF, false>), gb, dim3(256), 0, st, p, q, nblk_k);                      \
+    if (stream_b) {                                                                                                     \
+      if (rounding == SAGE_ROUND_TRITON) hipLaunchKernelGGL((kv_quant_stream_kernel<DD, BF, true>), gb, dim3(256), 0, st, p, q, per_k, nwg_k, per_v);  \
+      else hipLaunchKernelGGL((kv_quant_stream_kernel<DD, BF, false>), gb, dim3(256), 0, st, p, q, per_k, nwg_k, per_v); \
+    } else {                                                                                                            \
+      if (rounding == SAGE_ROUND_TRITON) hipLaunchKernelGGL((kv_quant_kernel<DD, BF, true>), gb1, dim3(256), 0, st, p, q, nblk_k);  \
+      else hipLaunchKernelGGL((kv_quant_kernel<DD, BF, false>), gb1, dim3(256), 0, st, p, q, nblk_k);                   \
+    }                                                                                                                   \
   } while (0)
   const bool bf = dtype == SAGE_BF16;
   if (D == 64) { if (bf) LA(64, true); else LA(64, false); } else { if (bf) LA(128, true); else LA(128, false); }

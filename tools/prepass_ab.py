@@ -43,11 +43,11 @@ for (B, H, N, D) in shapes:
         vs = torch.zeros(B, H, D, dtype=torch.float32, device="cuda")
         ws = torch.empty(max(1, l.sage_kv_prepare_fp8_workspace_bytes(B, H, N, D) // 4), dtype=torch.float32, device="cuda")
         vd = L.SageTensor(v8.data_ptr(), v8.stride(0), v8.stride(1), v8.stride(2))
-        def run_k():
+        def run_k(l=l, k8=k8, ks=ks, km=km, ws=ws):   # (defaults bind THIS build's objects: a plain closure would see the last build's)
             r = l.sage_k_smooth_quant(L.desc(k, "HND"), L.dtype_code(DT), B, H, N, D, L.desc(k8, "HND"), ks.data_ptr(),
                                       km.data_ptr(), gran, rounding, ws.data_ptr(), st)
             assert r == 0, r
-        def run_kv():
+        def run_kv(l=l, k8=k8, ks=ks, km=km, ws=ws, vd=vd, vs=vs):
             r = l.sage_kv_prepare_fp8(L.desc(k, "HND"), L.desc(v, "HND"), L.dtype_code(DT), B, H, N, D, L.desc(k8, "HND"),
                                       ks.data_ptr(), km.data_ptr(), gran, rounding, vd, vs.data_ptr(), 448.0, ws.data_ptr(), st)
             assert r == 0, r
@@ -57,7 +57,11 @@ for (B, H, N, D) in shapes:
         run_kv(); torch.cuda.synchronize()
         outs.append(o1 + (k8.clone(), ks.clone(), km.clone(), v8.clone(), vs.clone()))
         times.append((run_k, run_kv, [], []))
+    names = ("k8", "k_scale", "km", "kv:k8", "kv:k_scale", "kv:km", "kv:v8", "kv:v_scale")
+    diff = [f"{os.path.basename(libs[i + 1][0])}:{n}" for i, o in enumerate(outs[1:]) for n, x, y in zip(names, outs[0], o) if not torch.equal(x, y)]
+    same = not diff if not diff else "DIFFERENT: " + ",".join(diff)
     if a.once:
+        print(f"| ({B},{H},{N},{D}) | {same} |", flush=True)
         continue
     n = max(10, int(2e9 / (B * H * N * D * 5)))
     for rnd in range(5):
@@ -69,6 +73,5 @@ for (B, H, N, D) in shapes:
                 for _ in range(n): f()
                 e1.record(); torch.cuda.synchronize()
                 acc.append(e0.elapsed_time(e1) / n * 1e3)
-    same = all(all(torch.equal(x, y) for x, y in zip(outs[0], o)) for o in outs[1:])
     print(f"| ({B},{H},{N},{D}) | " + " | ".join(f"{statistics.median(tk):.1f} | {statistics.median(tkv):.1f}" for _, _, tk, tkv in times)
           + f" | {same} |", flush=True)
