@@ -506,27 +506,41 @@ __global__ __launch_bounds__(256, D == 64 ? 8 : 7) void kv_quant_kernel(const Qu
   }
   const int bx = blockIdx.x - nblk_k;
   const int tg = threadIdx.x / G::TPR, tc = threadIdx.x % G::TPR;
+  // the unit's rows first: the statistics below overlap with this trip to HBM
+  uint4 raw[4];
+  v_quant_load<D>(q.v + b * q.sb + h * q.sh, q.sn, p.N, bx, raw);
   if (tg < p.S) {  // one round trip for all chunks (S <= 16 <= token groups per workgroup)
     const float* pp = q.part + (((int64_t)b * H + h) * p.S + tg) * D + tc * 8;
     *reinterpret_cast<float4*>(&exch[tg][tc * 8]) = *reinterpret_cast<const float4*>(pp);
     *reinterpret_cast<float4*>(&exch[tg][tc * 8 + 4]) = *reinterpret_cast<const float4*>(pp + 4);
   }
   __syncthreads();
-  float mean[8], rcp[8], vs[8];
+  // the per-channel scale is finished by the FIRST token group and handed over through LDS (every thread doing it for itself:
+  // 8 S maxima and 16 IEEE divisions per thread for 32 elements of real work)
+  if (tg == 0) {  // (this thread alone reads columns tc*8 .. tc*8+7 of exch, so it may overwrite them in row 0)
+    float rc[8], vs[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float a = exch[0][tc * 8 + j];
-    for (int s_ = 1; s_ < p.S; ++s_) a = fmaxf(a, exch[s_][tc * 8 + j]);
-    mean[j] = 0.f;
-    rcp[j] = q.scale_max / a;   // v_stats_final_kernel
-    vs[j] = a / q.scale_max;
+    for (int j = 0; j < 8; ++j) {
+      float a = exch[0][tc * 8 + j];
+      for (int s_ = 1; s_ < p.S; ++s_) a = fmaxf(a, exch[s_][tc * 8 + j]);
+      rc[j] = q.scale_max / a;   // v_stats_final_kernel
+      vs[j] = a / q.scale_max;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) exch[0][tc * 8 + j] = rc[j];
+    if (bx == 0) {
+      float* o = q.v_scale + ((int64_t)b * H + h) * D + tc * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(vs[4], vs[5], vs[6], vs[7]);
+    }
   }
-  if (bx == 0 && tg == 0) {
-    float* o = q.v_scale + ((int64_t)b * H + h) * D + tc * 8;
-    *reinterpret_cast<float4*>(o) = make_float4(vs[0], vs[1], vs[2], vs[3]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(vs[4], vs[5], vs[6], vs[7]);
-  }
-  v_quant_transpose_body<D, BF16>(q.v, q.sb, q.sh, q.sn, p.N, mean, rcp, q.out, q.ob, q.oh, q.od, q.o_tile, bx, h, b, tile);
+  __syncthreads();
+  float mean[8], rcp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mean[j] = 0.f; rcp[j] = exch[0][tc * 8 + j]; }
+  v_quant_to_image<D, BF16>(raw, p.N, bx, mean, rcp, tile);
+  __syncthreads();
+  v_quant_store_image<D>(q.out, q.ob, q.oh, q.od, q.o_tile, p.N, bx, h, b, tile);
 }
 
 // Launch B as a STREAMING kernel for long sequences (round 3; sage_kv_prepare_fp8 picks by the units a workgroup would walk): workgroups [0, nwg_k) walk per_k consecutive K blocks
