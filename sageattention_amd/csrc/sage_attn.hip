@@ -1346,7 +1346,13 @@ static int run_attn(const sage_tensor* q8, const sage_tensor* k8, const sage_ten
   // heavier prologue moves the crossover out -- 4-wave 0.959x the 8-wave time at 2048 keys, 0.979x at 3072, 0.998x at 4096,
   // 1.02x from 6144; causal 0.993x at 8192 (4096 keys per row on average) -> 4 waves up to 3072 keys per row.
   const int keys_per_row = is_causal ? N / 2 : N;
-  const int nw = g_nwaves_override ? g_nwaves_override : ((D == 64 || pv_fp8 || keys_per_row <= 3072) ? 4 : 8);
+  // FP8 PV at head_dim 128, end of round 3 (tools/ab_bench.py --pv fp8 lib@4 lib@8, non-causal): 4-wave workgroups +2.2 % at 8K
+  // keys, +0.7 % at 16K, -1.1 % at 32K, -1.3 % at 64K.  The two co-resident 4-wave workgroups of a CU drift apart on a long
+  // stream (the older one wins the issue arbitration) until they no longer share K/V tiles in L2: FETCH_SIZE of one rank's launch
+  // of the 64K-key gather schedule (8192 rows x 65536 keys) is 1.90x the algorithmic bytes with 4 waves and 1.00x with 8
+  // (profiles/r03_ab/fetch_by_geometry.md) -> 8 waves beyond 24K keys per row.
+  const int nw = g_nwaves_override ? g_nwaves_override
+                                   : ((D == 64 || (pv_fp8 && keys_per_row <= 24576) || keys_per_row <= 3072) ? 4 : 8);
   p.nqb = (M + nw * 32 - 1) / (nw * 32);
 #define SAGE_GO(DD, NW) (pv_fp8 ? launch_attn<DD, NW, true>(p, is_causal, kthread, false, st) : launch_attn<DD, NW, false>(p, is_causal, kthread, vb, st))
   if (nw == 8) return D == 64 ? SAGE_GO(64, 8) : SAGE_GO(128, 8);

@@ -21,7 +21,7 @@ B, H, N, D, causal = {"c2": (4, 32, 2048, 64, False), "c3": (4, 32, 8192, 128, F
                       "c2c": (4, 32, 2048, 64, True), "c16k": (2, 32, 16384, 128, False),
                       "d64_8k": (4, 32, 8192, 64, False), "c3s": (1, 32, 8192, 128, False), "c3xs": (1, 8, 8192, 128, False),
                       "c3l": (8, 32, 8192, 128, False), "d128_1k": (16, 32, 1024, 128, False), "d128_1536": (8, 32, 1536, 128, False), "d128_2k": (8, 32, 2048, 128, False), "d128_3k": (4, 32, 3072, 128, False), "d128_4kc": (4, 32, 4096, 128, True), "d128_4k": (4, 32, 4096, 128, False), "d128_6k": (4, 32, 6144, 128, False), "c16kc": (2, 32, 16384, 128, True), "d128_2kc": (8, 32, 2048, 128, True),
-                      "c4": (4, 32, 16384, 128, True)}[a.wl]
+                      "c4": (4, 32, 16384, 128, True), "c32k": (1, 32, 32768, 128, False), "c64k": (1, 16, 65536, 128, False)}[a.wl]
 torch.manual_seed(0)
 DT = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 EL = 0 if a.dtype == "fp16" else 1   # SAGE_F16 / SAGE_BF16
