@@ -74,9 +74,10 @@ void attn_i8_kernel(const AttnParams p) {
   const int bh = lid / p.nqb;
   const int h = bh % p.Hq, b = bh / p.Hq;
   // Causal: heaviest q-blocks of a head first (load balance at the end of the grid).  An XCD holds fewer workgroups than
-  // a long head has q-blocks, so a head runs in two generations and the second re-reads part of K/V (C4: 1.32x the
-  // algorithmic HBM traffic, at 0.35 TB/s).  The opposite order, meant to let the second generation find the first one's
-  // tiles in L2, was measured: 1-2 % slower on every causal shape and FETCH_SIZE went UP (742 vs 604 MB at C4).
+  // a long head has q-blocks, so a head runs in two generations and the second starts again at key 0 (C4 reads 2.06x its
+  // K/V + Q bytes from the HBM side, 1.72x with 8-wave workgroups: profiles/r03_ab/fetch_by_geometry.md; at 0.35 TB/s).
+  // The opposite order, meant to let the second generation find the first one's tiles in L2, was measured: 1-2 % slower
+  // on every causal shape and FETCH_SIZE went UP (742 vs 604 MB at C4).
   if constexpr (CAUSAL && !abl::kLightFirst) qb = p.nqb - 1 - qb;
   const int hk = h / (p.Hq / p.Hk);
   int M_ = p.M, N_ = p.N;
