@@ -810,13 +810,15 @@ def test_k_smooth_quant_is_bit_identical_to_mean_plus_quantizer(sa, layout, dt):
 @pytest.mark.parametrize("layout", ["HND", "NHD"])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_kv_prepare_fp8_is_bit_identical_to_the_separate_quantizers(sa, layout, dt):
-    """sage_kv_prepare_fp8 (K smoothing + INT8 and the FP8 V^T in one call: two launches up to 16 chunks of 256 rows, where
-    both quantizers finish their own statistics; the separate kernels beyond) against sage_k_smooth_quant and
+    """sage_kv_prepare_fp8 (K smoothing + INT8 and the FP8 V^T in one call of two launches; launch B one unit per workgroup
+    or, with enough work, the streaming kernel) against sage_k_smooth_quant and
     sage_quant_v_fp8 without V smoothing: every output bit-identical, ragged / single-row / long shapes, V outliers."""
     from sageattention_amd import _lib as L
     from sageattention_amd.quant import k_smooth_quant, kv_prepare_fp8, per_channel_fp8
     for i, (B, H, N, D) in enumerate([(1, 1, 1, 64), (2, 3, 63, 128), (1, 2, 257, 64), (2, 4, 1000, 128), (1, 5, 4096, 64),
-                                      (2, 2, 4096, 128), (1, 2, 4097, 128), (1, 4, 8192, 64), (3, 2, 2050, 64)]):
+                                      (2, 2, 4096, 128), (1, 2, 4097, 128), (1, 4, 8192, 64), (3, 2, 2050, 64),
+                                      # enough (b, h, unit) work for the STREAMING K + V quantizer (several units per workgroup), ragged tails
+                                      (4, 32, 2050, 64), (3, 40, 4100, 128), (2, 64, 8191, 128)]):
         g = torch.Generator(device="cuda").manual_seed(700 + i)
         shape = (B, H, N, D) if layout == "HND" else (B, N, H, D)
         k = (torch.randn(shape, device="cuda", generator=g) * 2 + torch.randn((1, 1, 1, D), device="cuda", generator=g) * 3).to(dt)
