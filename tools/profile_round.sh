@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in c3 c2 c4; do
-  # bench.py's OWN windows (c2: 200 timed steps after 20 warm-up steps -- the steady state its JSON line quotes; c3/c4: 20 + 5)
+  # bench.py's OWN windows (c2: 200 timed steps after 20 warm-up steps -- the steady state its JSON line quotes; c3/c4: 100 + 20)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$wl -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-fa2 > $OUT/kt_$wl.log 2>&1
   cp $(ls $OUT/kt_$wl/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${wl}_kernel_stats.csv
   grep "^{" $OUT/kt_$wl.log | tail -1 > $OUT/${TAG}_bench_${wl}_under_tracer.json   # (the tracer prints after the bench: not the last line)
