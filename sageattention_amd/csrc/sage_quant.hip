@@ -2,6 +2,9 @@
 //   K0  k_mean            (replaces torch k.mean at sageattention/core.py:612)
 //   K1  quant_qk_int8     (replaces QuantInt8Kernel csrc/fused/fused.cu:64-198 and the Triton
 //                          quantizers sageattention/triton/quant_per_{block,thread}.py)
+//                         one block per workgroup (quant_qk_int8_kernel) or, for dense K, several consecutive blocks of a
+//                         head per workgroup with the next block's rows prefetched (k_quant_stream_kernel); with the FP8 V
+//                         quantizer in one launch: kv_quant_kernel / kv_quant_stream_kernel
 //   K2  sub_mean_f16      (replaces SubMeanKernel csrc/fused/fused.cu:200-260)
 // Roofline: HBM. Algorithmic traffic per element: 2 B read + 1 B written (K1), 2 B read (K0).
 // Every thread moves 16 B per load (8 fp16/bf16), the widest coalesced access on CDNA4.
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256, D == 64 ? 5 : 4) void k_quant_stream_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused K/V pre-pass of the FP8-PV operator for sequences of at most 16 chunks (4096 rows): TWO launches instead of five
+// Fused K/V pre-pass of the FP8-PV operator, at every length (a sequence is at most 16 chunks, kmean_chunk_rows): TWO launches instead of five
 // (k_mean_partial, quantizer | v_stats_partial, v_stats_final, v_quant_transpose).  Every kernel below is bandwidth- or
 // latency-bound and fills the chip on its own, so what the fusion saves is three launch boundaries and the ramp / tail of
 // three kernels, and the VALU-heavy K quantizer shares the CUs with the bandwidth-bound V quantizer.
