@@ -768,8 +768,8 @@ void attn_i8_kernel(const AttnParams p) {
     maybe_rescale(mx_cur);
     if constexpr (!abl::kNoStage) {
       if constexpr (RING == 2) {
-        if (j + 2 < ntiles && !(abl::kHalfLds && (j & 1))) dma_k(j + 2, K_WR);
-        if ((!DYN || j + 1 < ntiles) && !(abl::kHalfLds && (j & 1))) load_v(j + 1, V_WR);
+        if (j + 2 < ntiles && !(abl::kHalfCopies && (j & 1))) dma_k(j + 2, K_WR);
+        if ((!DYN || j + 1 < ntiles) && !(abl::kHalfCopies && (j & 1))) load_v(j + 1, V_WR);
       } else {
         dma_k(min(j + RING, last_tile), K_WR);
         load_v(min(j + RING - 1, last_tile), V_WR);
@@ -879,7 +879,7 @@ void attn_i8_kernel(const AttnParams p) {
       const float c0 = __builtin_fmaf(-kBiasF, a0, kPOff - m_run), c1 = __builtin_fmaf(-kBiasF, a1, kPOff - m_run);
       auto k_frag = [&](const int i) __attribute__((always_inline)) -> v4i {
         if constexpr (abl::kNoLdsK) return qf[i % KS];
-        else if constexpr (abl::kHalfLds) { if (i & 1) return qf[i % KS]; else return *reinterpret_cast<const v4i*>(k_rd[i % KS] + (kb + (i / KS) * 32 * D)); }
+        else if constexpr (abl::kHalfReads) { if (i & 1) return qf[i % KS]; else return *reinterpret_cast<const v4i*>(k_rd[i % KS] + (kb + (i / KS) * 32 * D)); }
         else if constexpr (abl::kConstOdd) {
           const v4i f = *reinterpret_cast<const v4i*>(k_rd[i % KS] + (kb + (i / KS) * 32 * D));
           if (i & 1) { asm volatile("" :: "v"(f)); return qf[i % KS]; }
@@ -889,7 +889,7 @@ void attn_i8_kernel(const AttnParams p) {
       };
       auto v_frag = [&](const int q, const int dt) __attribute__((always_inline)) -> v8h {
         if constexpr (abl::kNoLdsV) return __builtin_bit_cast(v8h, qf[(q + dt) % KS]);
-        if constexpr (abl::kHalfLds) { if ((q + dt) & 1) return __builtin_bit_cast(v8h, qf[(q + dt) % KS]); }
+        if constexpr (abl::kHalfReads) { if ((q + dt) & 1) return __builtin_bit_cast(v8h, qf[(q + dt) % KS]); }
         const char* base = v_rd[dt] + (vb + 16 * q * (2 * D));
         const v4s_vs lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base));
         const v4s_vs hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_vs*)(base + 8 * (2 * D)));

@@ -47,10 +47,14 @@ SAGE_ABL_FLAG(kNoLdsV, true);
 #else
 SAGE_ABL_FLAG(kNoLdsV, false);
 #endif
-#ifdef SAGE_ABL_HALFLDS    // fp16 stream: every second K / V^T fragment read and every second tile copy dropped -- what a wave
-SAGE_ABL_FLAG(kHalfLds, true);   // with TWO 32-row sub-tiles (fragments shared) would save per row, at today's occupancy
+#if defined(SAGE_ABL_HALFLDS)     // fp16 stream: every second K / V^T fragment read and every second tile copy dropped -- what a wave
+constexpr bool kHalfReads = true, kHalfCopies = true;   // with TWO 32-row sub-tiles (fragments shared) would save per row, at today's occupancy
+#elif defined(SAGE_ABL_HALFREADS) // ... only the fragment reads
+constexpr bool kHalfReads = true, kHalfCopies = false;
+#elif defined(SAGE_ABL_HALFCOPIES) // ... only the tile copies
+constexpr bool kHalfReads = false, kHalfCopies = true;
 #else
-SAGE_ABL_FLAG(kHalfLds, false);
+constexpr bool kHalfReads = false, kHalfCopies = false;
 #endif
 #ifdef SAGE_ABL_CONSTODD   // control of HALFLDS: every fragment is still READ and every tile copied, but every second MFMA is fed a
 SAGE_ABL_FLAG(kConstOdd, true);  // constant register instead (the share of HALFLDS's gain that is operand-toggle power, not LDS)
