@@ -614,7 +614,9 @@ void attn_i8_kernel(const AttnParams p) {
         const int mt = w >> 2, e0 = 4 * (w & 3);
         const float p0 = prob(mt, e0), p1 = prob(mt, e0 + 1), p2 = prob(mt, e0 + 2), p3 = prob(mt, e0 + 3);
         psum += p0; psum += p1; psum += p2; psum += p3;
-        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, 0, false);  // OCP e4m3, RNE (e4m3_rn_satfinite)
+        int pk = 0;
+        if constexpr (D == 128) asm volatile("" : "=v"(pk));  // (no v_mov for the `old` operand: see the hand-placed stream)
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, pk, false);  // OCP e4m3, RNE (e4m3_rn_satfinite)
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, pk, true);
         pb[w] = pk;
       }
@@ -814,7 +816,11 @@ void attn_i8_kernel(const AttnParams p) {
           const bool g1 = ((e0 + i) & 2) != 0;
           pend[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(__int_as_float(sa[mt][e0 + i]), g1 ? a1 : a0, g1 ? c1 : c0));
         }
-        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[0], pend[1], 0, false);  // OCP e4m3, RNE
+        // (the first convert's `old` operand is a register nobody has written: both halves of the dword are produced by the two
+        //  converts, and a literal 0 there costs a v_mov_b32 per P word -- 8 of ~166 vector instructions per tile)
+        int pk = 0;
+        if constexpr (D == 128) asm volatile("" : "=v"(pk));  // (head_dim 64: the variants at the 168-register line spill with it)
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[0], pend[1], pk, false);  // OCP e4m3, RNE
         pk = __builtin_amdgcn_cvt_pk_fp8_f32(pend[2], pend[3], pk, true);
         pb[w] = pk;
       };

@@ -66,7 +66,9 @@ __device__ __forceinline__ void v_quant_to_image(const uint4 (&raw)[4], int N, i
   const int pos_dw = 8 * hh + 4 * mt + (w0 >> 3);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0][j], x[1][j], 0, false);  // OCP e4m3fn, RNE, saturating
+    int pk;
+    asm("" : "=v"(pk));  // (`old` of the first convert: both halves are written, a literal 0 would cost a v_mov_b32)
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0][j], x[1][j], pk, false);  // OCP e4m3fn, RNE, saturating
     pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[2][j], x[3][j], pk, true);
     const int d = tc * 8 + j;
     tile[bi * IMG + d * 16 + 4 * (d >> 3) + pos_dw] = (uint32_t)pk;
